@@ -1,0 +1,247 @@
+"""Generate tests/golden/*.npz|json by running the REFERENCE's own modules.
+
+Run in the build container only (it reads /root/reference, which does not exist on the GPU
+box):   python tests/golden/make_goldens.py
+
+The fixtures hold data only: seeds/parameters of the inputs (regenerated anywhere with
+style_transfer_amd.synth), the reference's outputs, and the reference's mask files packed
+to bits.  Harness adjustments, none of which edits a reference file:
+  * torch.Tensor.cuda is made a no-op: ldm/modules/attention.py:270 hard-codes .cuda()
+  * the mask is written to <tmp>/x_mask.npy and cnt_name='<tmp>/x.jpg', the path the
+    reference derives at ldm/modules/attention.py:410-411
+  * to_q / to_out are set to identity (or to seeded weights in the 'module' cases) so the
+    fixture pins the attention arithmetic itself
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from style_transfer_amd import synth  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+import ldm.modules.attention as ref_attn  # noqa: E402
+import high_frequency_final as ref_hf  # noqa: E402
+from ldm.modules.diffusionmodules.util import make_ddim_timesteps  # noqa: E402
+
+MASK_DIR = os.path.join(REF, "dataset_ours", "mask")
+MASK_NAMES = sorted(f[:-4] for f in os.listdir(MASK_DIR) if f.endswith(".npy"))
+
+
+def ref_mask_downsample(mask512, r_h, r_w, ch):
+    """Literal replay of ldm/modules/attention.py:270-283 for one mask."""
+    mask = torch.tensor(mask512, dtype=torch.float32).cuda()
+    mask[mask < 0.5] = -1.0
+    mask[mask > 0.5] = 1.0
+    mask = mask * ch
+    mask = mask.unsqueeze(0).unsqueeze(0)
+    mask = torch.nn.functional.interpolate(mask, size=(r_h, r_w), mode="bilinear", align_corners=False)
+    return mask.reshape(-1).numpy().copy()
+
+
+def gen_masks():
+    packed, down = {}, {}
+    for nm in MASK_NAMES:
+        m = np.load(os.path.join(MASK_DIR, nm + ".npy"))
+        assert m.shape == (512, 512) and m.dtype == np.float32
+        assert set(np.unique(m)) <= {0.0, 1.0}
+        packed[nm] = np.packbits(m.astype(np.uint8))
+        for r in (128, 64, 32, 16, 8):
+            pos = ref_mask_downsample(m, r, r, 1.0)
+            neg = ref_mask_downsample(m, r, r, -1.0)
+            assert np.array_equal(neg, -pos)
+            down[f"{nm}/{r}"] = pos
+    dv = np.load(os.path.join(REF, "data_vis", "cnt", "content_flower_mask.npy"))
+    assert np.array_equal(dv, np.load(os.path.join(MASK_DIR, "content_flower_mask.npy")))
+    np.savez_compressed(os.path.join(HERE, "masks_packed.npz"), **packed)
+    np.savez_compressed(os.path.join(HERE, "mask_downsample.npz"), **down)
+    # general bilinear weights: grey, non-power-of-two, non-square
+    gen = {}
+    specs = [(500, 500, 64, 64, 11), (512, 512, 48, 48, 12), (300, 420, 37, 53, 13), (512, 512, 96, 96, 14),
+             (64, 64, 64, 64, 15), (40, 40, 64, 64, 16)]
+    for (ih, iw, oh, ow, seed) in specs:
+        g = synth.uniform(seed, (ih, iw))
+        g[::7, ::5] = 0.5          # exact 0.5 stays 0.5 (neither comparison fires)
+        for ch in (1.0, -1.0):
+            gen[f"{ih}x{iw}_{oh}x{ow}_s{seed}_ch{int(ch)}"] = ref_mask_downsample(g, oh, ow, ch)
+    np.savez_compressed(os.path.join(HERE, "mask_general.npz"), **gen)
+    print("masks:", len(packed), "files;", len(down), "downsamples;", len(gen), "general")
+
+
+def mask_for(kind):
+    if kind == "disc":
+        return synth.disc_mask()
+    if kind == "half":
+        return synth.half_plane_mask()
+    return np.load(os.path.join(MASK_DIR, kind + ".npy"))
+
+
+def make_module(heads, d, identity=True, wseed=0):
+    mod = ref_attn.CrossAttention(query_dim=heads * d, heads=heads, dim_head=d)
+    C = heads * d
+    with torch.no_grad():
+        if identity:
+            mod.to_q.weight.copy_(torch.eye(C))
+            mod.to_k.weight.copy_(torch.eye(C))
+            mod.to_v.weight.copy_(torch.eye(C))
+            mod.to_out[0].weight.copy_(torch.eye(C))
+            mod.to_out[0].bias.zero_()
+        else:
+            s = 1.0 / np.sqrt(C)
+            mod.to_q.weight.copy_(torch.from_numpy(synth.normal(wseed + 1, (C, C), s)))
+            mod.to_k.weight.copy_(torch.from_numpy(synth.normal(wseed + 2, (C, C), s)))
+            mod.to_v.weight.copy_(torch.from_numpy(synth.normal(wseed + 3, (C, C), s)))
+            mod.to_out[0].weight.copy_(torch.from_numpy(synth.normal(wseed + 4, (C, C), s)))
+            mod.to_out[0].bias.copy_(torch.from_numpy(synth.normal(wseed + 5, (C,), 0.1)))
+    return mod.eval()
+
+
+def run_case(tmp, case):
+    H, N, d = case["heads"], case["N"], case["d"]
+    t = synth.attention_inputs(case["seed"], H, N, d, case["sigma_qk"], case["sigma_v"])
+    T = {k: torch.from_numpy(v) for k, v in t.items()}
+    mod = make_module(H, d, identity=not case.get("module_weights", False), wseed=case["seed"] * 100)
+    mask_kind = case["mask"]
+    base = os.path.join(tmp, f"c{case['id']}")
+    if mask_kind != "none":
+        np.save(base + "_mask.npy", mask_for(mask_kind))
+    mod.cnt_name = base + ".jpg"
+    cfg = None if case["T"] is None else {"T": case["T"], "gamma": case["gamma"]}
+    x = T["xq"]                       # (1, N, H*d); with identity to_q this IS to_q(x)
+    branch = case["branch"]
+    with torch.no_grad():
+        if branch == "injected":
+            out = mod(x, q_injected=T["q_cnt"], k_injected=T["k1"], v_injected=T["v1"],
+                      cnt_k_injected=T["k_cnt"], sty_q_injected=None, cnt_v_injected=T["v_cnt"],
+                      sty2_q_injected=None, sty2_k_injected=T["k2"], sty2_v_injected=T["v2"],
+                      injection_config=cfg)
+        elif branch == "styleid_nomask":      # attention.py:569-579, q,k,v injected, no mask file
+            out = mod(x, q_injected=T["q_cnt"], k_injected=T["k1"], v_injected=T["v1"], injection_config=cfg)
+        elif branch in ("tplain", "plain"):   # attention.py:556-566 (mask present) / 569-579 (none)
+            out = mod(x, injection_config=cfg)
+        elif branch == "genpkl":              # attention.py:584-604
+            mod.gen_pkl = True
+            out = mod(x)
+        else:
+            raise ValueError(branch)
+    return out[0].numpy()
+
+
+def attn_cases():
+    cases = []
+    cid = 0
+    shapes = [(64, 160), (256, 160), (1024, 80), (4096, 40)]
+    combos = [(0.5, 1.5, 1.0, "content_flower_mask"), (0.75, 1.5, 2.0, "content_flower_mask"),
+              (0.5, 1.0, 1.0, "disc"), (0.75, 1.0, 2.0, "half"), (0.75, 1.5, 1.0, "content_car_mask")]
+    for (N, d) in shapes:
+        for (gamma, T, sig, mk) in combos:
+            if N == 4096 and mk == "content_car_mask":
+                continue
+            cases.append(dict(id=cid, branch="injected", heads=8, N=N, d=d, gamma=gamma, T=T,
+                              sigma_qk=sig, sigma_v=1.0, mask=mk, seed=100 + cid)); cid += 1
+    # other branches
+    for (N, d) in [(64, 160), (256, 160), (1024, 80)]:
+        cases.append(dict(id=cid, branch="tplain", heads=8, N=N, d=d, gamma=0.75, T=1.5, sigma_qk=1.0,
+                          sigma_v=1.0, mask="content_flower_mask", seed=100 + cid)); cid += 1
+        cases.append(dict(id=cid, branch="plain", heads=8, N=N, d=d, gamma=None, T=None, sigma_qk=1.0,
+                          sigma_v=1.0, mask="none", seed=100 + cid)); cid += 1
+        cases.append(dict(id=cid, branch="styleid_nomask", heads=8, N=N, d=d, gamma=0.75, T=1.5, sigma_qk=1.5,
+                          sigma_v=1.0, mask="none", seed=100 + cid)); cid += 1
+    cases.append(dict(id=cid, branch="genpkl", heads=8, N=256, d=160, gamma=None, T=None, sigma_qk=1.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid)); cid += 1
+    # whole-module cases (seeded to_q / to_out weights): pins the drop-in class end to end
+    cases.append(dict(id=cid, branch="injected", heads=8, N=256, d=40, gamma=0.75, T=1.5, sigma_qk=1.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid, module_weights=True)); cid += 1
+    cases.append(dict(id=cid, branch="tplain", heads=8, N=256, d=40, gamma=0.75, T=1.5, sigma_qk=1.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid, module_weights=True)); cid += 1
+    # odd head counts / sizes the kernels must not silently mishandle
+    cases.append(dict(id=cid, branch="injected", heads=4, N=144, d=24, gamma=0.6, T=2.0, sigma_qk=1.0,
+                      sigma_v=1.0, mask="disc", seed=100 + cid)); cid += 1
+    cases.append(dict(id=cid, branch="injected", heads=2, N=100, d=64, gamma=0.3, T=0.5, sigma_qk=1.0,
+                      sigma_v=1.0, mask="half", seed=100 + cid)); cid += 1
+    return cases
+
+
+def gen_attention():
+    cases = attn_cases()
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for c in cases:
+            out = run_case(tmp, c)             # (N, H*d)
+            N = c["N"]
+            if N <= 144:
+                rows = np.arange(N)
+            else:
+                # sampled rows: always include mask-boundary rows when there are any
+                rows = np.unique(np.concatenate([
+                    (synth.hash_u64(c["seed"], 24) % np.uint64(N)).astype(np.int64),
+                    np.array([0, N - 1, N // 2])]))
+                if c["mask"] != "none":
+                    side = int(round(np.sqrt(N)))
+                    m = ref_mask_downsample(mask_for(c["mask"]), side, side, 1.0)
+                    frac = np.nonzero(np.abs(m) != 1.0)[0]
+                    rows = np.unique(np.concatenate([rows, frac[:8]]))
+            c["rows"] = [int(r) for r in rows]
+            arrays[f"out_rows/{c['id']}"] = out[rows].astype(np.float32)
+            arrays[f"colsum/{c['id']}"] = out.astype(np.float64).sum(axis=0)
+            arrays[f"colsqsum/{c['id']}"] = (out.astype(np.float64) ** 2).sum(axis=0)
+            print("attn case", c["id"], c["branch"], c["N"], c["d"], "rows", len(rows),
+                  "absmax %.3f" % np.abs(out).max())
+    np.savez_compressed(os.path.join(HERE, "attention.npz"), **arrays)
+    with open(os.path.join(HERE, "attention_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
+def gen_hf():
+    arrays, cases = {}, []
+    cid = 0
+    for (B, C, Hh, Ww) in [(1, 4, 8, 8), (1, 4, 16, 16), (1, 8, 32, 32), (1, 8, 64, 64), (1, 4, 128, 128),
+                           (2, 3, 32, 32), (1, 2, 16, 64), (1, 2, 64, 32)]:
+        for ratio in (0.25, 0.5, 0.75):
+            seed = 500 + cid
+            h = synth.normal(seed, (B, C, Hh, Ww))
+            out = ref_hf.high_freq_filter(torch.from_numpy(h), radius_ratio=ratio).numpy()
+            arrays[f"hf/{cid}"] = out.astype(np.float32)
+            cases.append(dict(id=cid, shape=[B, C, Hh, Ww], ratio=ratio, seed=seed))
+            cid += 1
+    # zeroed-bin counts at ratio 0.5 (derived from the reference's mask construction)
+    counts = {}
+    for r in (8, 16, 32, 64, 128):
+        cy = cx = r // 2
+        radius = int(r * 0.5)
+        y = torch.arange(r).view(-1, 1); x = torch.arange(r).view(1, -1)
+        counts[str(r)] = int(((y - cy) ** 2 + (x - cx) ** 2 < radius ** 2).sum())
+    np.savez_compressed(os.path.join(HERE, "hf_filter.npz"), **arrays)
+    sched50 = make_ddim_timesteps("uniform", 50, 1000, verbose=False)
+    misc = dict(
+        hf_cases=cases, zeroed_bins_ratio_0p5=counts,
+        ddim_timesteps_50=[int(t) for t in sched50],
+        ddim_timesteps_20=[int(t) for t in make_ddim_timesteps("uniform", 20, 1000, verbose=False)],
+        content_injection_schedule_50=[int(t) for t in ref_hf.make_content_injection_schedule(sched50)],
+        content_injection_schedule_50_a25=[int(t) for t in ref_hf.make_content_injection_schedule(sched50, 0.25)],
+    )
+    with open(os.path.join(HERE, "hf_cases.json"), "w") as f:
+        json.dump(misc, f, indent=1)
+    print("hf:", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["masks", "hf", "attention"]
+    if "masks" in which:
+        gen_masks()
+    if "hf" in which:
+        gen_hf()
+    if "attention" in which:
+        gen_attention()
