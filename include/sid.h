@@ -1,0 +1,131 @@
+/*
+ * sid.h -- C ABI of libsid.so: the mask-based multi-style injection path on MI355X (gfx950).
+ *
+ * The reference implementation is pure Python/PyTorch and has no FFI; each entry point below
+ * replaces the tensor arithmetic of one reference call site (cited per function, paths
+ * relative to the reference repository root).  A binding needs only plain pointers and sizes.
+ *
+ * Conventions
+ *   - Every tensor pointer is DEVICE memory on the current HIP device; the caller owns it.
+ *   - Inputs are never written.  Work is enqueued on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); no entry point synchronises, allocates or frees.
+ *   - Return value: SID_OK, or a negative errno-style code; sid_last_error() then returns a
+ *     thread-local description.  Nothing is enqueued when an argument check fails.
+ *   - Scratch memory is supplied by the caller: ask sid_*_workspace_bytes() and pass a
+ *     256-byte aligned buffer at least that large.
+ */
+#ifndef SID_H
+#define SID_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SID_VERSION 100 /* 0.1.0 */
+
+/* return codes */
+#define SID_OK 0
+#define SID_EINVAL (-22) /* bad argument (shape, dtype, alignment, NULL) */
+#define SID_ENOMEM (-12) /* workspace too small */
+#define SID_ENOSYS (-38) /* valid request this build has no kernel for */
+#define SID_EIO (-5)     /* HIP runtime error at launch */
+
+/* storage type of the q/k/v/out tensors */
+#define SID_DTYPE_F32 0
+#define SID_DTYPE_BF16 1
+
+/* arithmetic of the two matrix products inside the attention kernels */
+#define SID_COMPUTE_BF16 0  /* bf16 MFMA operands, f32 accumulate: <= 2e-2 relative */
+#define SID_COMPUTE_F32X3 1 /* split-bf16 (hi+lo) 3-product MFMA, f32-grade: <= 1e-3 relative */
+
+/* memory layout of a (batch, heads, tokens, head_dim) tensor; head_dim is always contiguous */
+#define SID_LAYOUT_BHND 0 /* (B*H, N, d) contiguous: the precomputed feature lists            */
+#define SID_LAYOUT_BNHD 1 /* (B, N, H*d) contiguous: the output of a Linear projection        */
+
+/* flags (bit mask) */
+#define SID_FLAG_BLOCK_SKIP 1 /* reserved: skip key blocks whose weight underflows f32 */
+
+const char* sid_last_error(void);
+int sid_version(void);
+
+/*
+ * Injected three-block self-attention.
+ * Replaces ldm/modules/attention.py:370-381 (query blend), :201-207 (content logits),
+ * :210-329 x2 (style logits + per-row mask bias), :538-546 (concat softmax, PV, head merge)
+ * of CrossAttention.forward; to_q before and to_out after stay with the caller.
+ *
+ *   x_q         (B, N, H*d)   to_q(x) of the current latent            [SID_LAYOUT_BNHD]
+ *   q_cnt       (B*H, N, d)   content query        (q_injected)
+ *   k1, v1      (B*H, N, d)   character style      (k_injected, v_injected)
+ *   k2, v2      (B*H, N, d)   background style     (sty2_k_injected, sty2_v_injected)
+ *   k_cnt,v_cnt (B*H, N, d)   content              (cnt_k_injected, cnt_v_injected)
+ *   mask_signed (B, N) f32    per-token mask from sid_mask_downsample with ch=+1:
+ *                             +1 character ... -1 background
+ *   out         (B, N, H*d)   'h (b n) d -> b n (h d)' result, input of to_out
+ *
+ *   q      = q_cnt*gamma + x_q*q_self_coef          (reference: q_self_coef is the literal 0.5)
+ *   logits = [ (q k1^T)*T*scale + b1 | (q k2^T)*T*scale + b2 | (q_cnt k_cnt^T)*scale ]
+ *   b1 = (min_j cc - max_j q k1^T) * (-mask),  b2 = (min_j cc - max_j q k2^T) * (+mask)
+ *   out = softmax(logits) [v1; v2; v_cnt]
+ * The N x 3N logits are never written to memory.
+ */
+size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, int compute);
+
+int sid_injected_attn_fwd(const void* x_q, const void* q_cnt,
+                          const void* k1, const void* v1,
+                          const void* k2, const void* v2,
+                          const void* k_cnt, const void* v_cnt,
+                          const float* mask_signed, void* out,
+                          int B, int H, int N, int d,
+                          float gamma, float q_self_coef, float T, float scale,
+                          int dtype, int compute, int flags,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Single-block attention  out = softmax((q k^T) * logit_scale) v.
+ * Replaces ldm/modules/attention.py:556-566 (mask present, not injected: logit_scale = T*scale),
+ * :569-579 (no mask file / cross-attention: T*scale if anything was injected, else scale) and
+ * :584-604 without the boolean `mask` fill (gen_pkl: scale).
+ *   q (B,H,Nq,d), k,v (B,H,Nk,d) in q_layout / kv_layout;  out (B, Nq, H*d).
+ */
+size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, int d, int compute);
+
+int sid_plain_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                       int B, int H, int Nq, int Nk, int d, float logit_scale,
+                       int q_layout, int kv_layout,
+                       int dtype, int compute, int flags,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Content mask -> signed per-token mask.
+ * Replaces ldm/modules/attention.py:270-284: threshold (<0.5 -> -1, >0.5 -> +1, ==0.5 kept),
+ * multiply by ch, bilinear resize (align_corners=False, no antialias) to (Hout, Wout).
+ *   mask (Hin, Win) f32 in [0,1];  out (Hout*Wout) f32.  Bit-exact with the reference for
+ *   its inputs (binary 512x512 masks, power-of-two outputs).
+ */
+int sid_mask_downsample(const float* mask, int Hin, int Win, int Hout, int Wout, float ch,
+                        float* out, void* stream);
+
+/*
+ * High-frequency radius filter, optionally fused with the patched ResBlock sum.
+ * Replaces high_frequency_final.py:4-36 (fft2 ortho, shift, zero the disc
+ * (y-H/2)^2+(x-W/2)^2 < int(min(H,W)*ratio)^2, unshift, ifft2, real part) and :82-88
+ * (out = out_skip + out_h + HF(h_cnt)).
+ *   h_cnt (B,C,H,W); skip, h (B,C,H,W) or both NULL for the bare filter; out (B,C,H,W).
+ *   H and W powers of two in [8, 128].
+ */
+int sid_hf_filter(const void* h_cnt, const void* skip, const void* h, void* out,
+                  int B, int C, int H, int W, float ratio, int dtype, void* stream);
+
+/* Same, with the disc radius given as the integer the reference computes on the host,
+ * int(min(H,W) * radius_ratio) (high_frequency_final.py:18), so that a binding that holds the
+ * ratio as a double truncates exactly as the reference does. */
+int sid_hf_filter_radius(const void* h_cnt, const void* skip, const void* h, void* out,
+                         int B, int C, int H, int W, int radius, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SID_H */

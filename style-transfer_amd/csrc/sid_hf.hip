@@ -1,0 +1,254 @@
+// High-frequency radius filter: LDS-resident 2-D FFT -> zero the low-frequency disc -> inverse FFT,
+// fused with the patched ResBlock sum  out = skip + h + HF(h_cnt).
+//
+// One 256-thread workgroup filters TWO feature maps at once as one complex map z = a + i*b: the
+// keep-mask is real and even in frequency, so it filters the real and imaginary parts
+// independently and two real transforms cost one complex transform.  The whole H x W complex map
+// stays in LDS (128x128: 129 KB); HBM sees each input once and the output once.
+//
+// A length-N transform runs across the lanes of a wave (one element per lane, two for N = 128) as
+// radix-2 butterflies exchanged with wavefront shuffles.  Forward passes are decimation in
+// frequency (natural in, bit-reversed out), inverse passes decimation in time (bit-reversed in,
+// natural out), so no reordering pass exists: the mask is simply evaluated at the bit-reversed
+// bin each lane holds.  No fftshift is needed either: bin k carries the signed frequency
+// f = k (k < N/2) else k - N, and the disc test is fy^2 + fx^2 < radius^2.
+#include "sid_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float2 shfl_xor2(float2 v, int m) {
+    return make_float2(__shfl_xor(v.x, m), __shfl_xor(v.y, m));
+}
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n / 2); }
+
+// Length-N transform over the lanes of a wave.  T[k] = exp(-2*pi*i*k/128), k < 64.
+template <int N>
+struct LaneFFT {
+    static constexpr int E = N > 64 ? N / 64 : 1;   // elements per lane (positions pos + 64e)
+    static constexpr int L = N > 64 ? 64 : N;       // lanes per transform
+
+    static __device__ __forceinline__ int bin(int p) { return (int)(__brev((unsigned)p) >> (32 - ilog2(N))); }
+
+    static __device__ __forceinline__ void fwd(float2 (&v)[E], int pos, const float2* T) {
+        if (E == 2) {
+            const float2 a = v[0], b = v[E - 1];
+            v[0] = cadd(a, b);
+            v[E - 1] = cmul(csub(a, b), T[pos]);
+        }
+#pragma unroll
+        for (int h = L / 2; h >= 1; h >>= 1) {
+            const bool up = (pos & h) != 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float2 o = shfl_xor2(v[e], h);
+                float2 s = up ? csub(o, v[e]) : cadd(v[e], o);
+                if (h > 1) {
+                    const float2 tw = T[(pos & (h - 1)) * (64 / h)];
+                    const float2 st = cmul(s, tw);
+                    s = up ? st : s;
+                }
+                v[e] = s;
+            }
+        }
+    }
+
+    static __device__ __forceinline__ void inv(float2 (&v)[E], int pos, const float2* T) {
+#pragma unroll
+        for (int h = 1; h <= L / 2; h <<= 1) {
+            const bool up = (pos & h) != 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float2 x = v[e];
+                if (h > 1) {
+                    const float2 xt = cmulc(x, T[(pos & (h - 1)) * (64 / h)]);
+                    x = up ? xt : x;
+                }
+                const float2 o = shfl_xor2(x, h);
+                v[e] = up ? csub(o, x) : cadd(x, o);
+            }
+        }
+        if (E == 2) {
+            const float2 a = v[0], b = cmulc(v[E - 1], T[pos]);
+            v[0] = cadd(a, b);
+            v[E - 1] = csub(a, b);
+        }
+    }
+};
+
+template <bool BF16>
+__device__ __forceinline__ float ld(const void* p, size_t i) {
+    if (BF16) return (float)((const __bf16*)p)[i];
+    return ((const float*)p)[i];
+}
+
+template <int H, int W, bool BF16>
+__global__ void __launch_bounds__(256) hf_kernel(const void* __restrict__ hcnt, const void* __restrict__ skip,
+                                                 const void* __restrict__ hres, void* __restrict__ out, int C,
+                                                 int pairs_per_b, int radius2) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    float2* T = sm;
+    float2* buf = sm + 64;
+    constexpr int LDW = W + 1;
+    using RF = LaneFFT<W>;
+    using CF = LaneFFT<H>;
+    constexpr int RPW = 64 / RF::L;   // rows a wave transforms at once
+    constexpr int CPW = 64 / CF::L;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        float s, c;
+        sincospif(-(float)tid / 64.0f, &s, &c);
+        T[tid] = make_float2(c, s);
+    }
+    const int b = blockIdx.x / pairs_per_b, pc = blockIdx.x % pairs_per_b;
+    const int c0 = 2 * pc;
+    const bool two = c0 + 1 < C;
+    const size_t base_a = ((size_t)b * C + c0) * H * W;
+    const size_t base_b = base_a + (size_t)H * W;
+    __syncthreads();
+
+    // rows, forward
+    for (int rg = wave; rg < H / RPW; rg += 4) {
+        const int y = rg * RPW + lane / RF::L, pos = lane % RF::L;
+        float2 v[RF::E];
+#pragma unroll
+        for (int e = 0; e < RF::E; ++e) {
+            const size_t o = (size_t)y * W + pos + 64 * e;
+            v[e] = make_float2(ld<BF16>(hcnt, base_a + o), two ? ld<BF16>(hcnt, base_b + o) : 0.f);
+        }
+        RF::fwd(v, pos, T);
+#pragma unroll
+        for (int e = 0; e < RF::E; ++e) buf[y * LDW + pos + 64 * e] = v[e];
+    }
+    __syncthreads();
+
+    // columns: forward, mask (and 1/(H*W) of the two ortho norms), inverse
+    constexpr float norm = 1.0f / (float)(H * W);
+    for (int cg = wave; cg < W / CPW; cg += 4) {
+        const int x = cg * CPW + lane / CF::L, pos = lane % CF::L;
+        float2 v[CF::E];
+#pragma unroll
+        for (int e = 0; e < CF::E; ++e) v[e] = buf[(pos + 64 * e) * LDW + x];
+        CF::fwd(v, pos, T);
+        const int kx = RF::bin(x);
+        const int fx = kx < W / 2 ? kx : kx - W;
+#pragma unroll
+        for (int e = 0; e < CF::E; ++e) {
+            const int ky = CF::bin(pos + 64 * e);
+            const int fy = ky < H / 2 ? ky : ky - H;
+            const float g = (fy * fy + fx * fx >= radius2) ? norm : 0.f;
+            v[e] = make_float2(v[e].x * g, v[e].y * g);
+        }
+        CF::inv(v, pos, T);
+#pragma unroll
+        for (int e = 0; e < CF::E; ++e) buf[(pos + 64 * e) * LDW + x] = v[e];
+    }
+    __syncthreads();
+
+    // rows, inverse; real part -> map a, imaginary part -> map b; fused residual sum
+    for (int rg = wave; rg < H / RPW; rg += 4) {
+        const int y = rg * RPW + lane / RF::L, pos = lane % RF::L;
+        float2 v[RF::E];
+#pragma unroll
+        for (int e = 0; e < RF::E; ++e) v[e] = buf[y * LDW + pos + 64 * e];
+        RF::inv(v, pos, T);
+#pragma unroll
+        for (int e = 0; e < RF::E; ++e) {
+            const size_t o = (size_t)y * W + pos + 64 * e;
+            if (BF16) {
+                __bf16* op = (__bf16*)out;
+                __bf16 ra = (__bf16)v[e].x, rb = (__bf16)v[e].y;
+                if (skip) {
+                    // bf16 tensors: (skip + h) rounds to bf16, then + HF rounds again
+                    const __bf16 sa = (__bf16)(ld<true>(skip, base_a + o) + ld<true>(hres, base_a + o));
+                    ra = (__bf16)((float)sa + (float)ra);
+                    if (two) {
+                        const __bf16 sb = (__bf16)(ld<true>(skip, base_b + o) + ld<true>(hres, base_b + o));
+                        rb = (__bf16)((float)sb + (float)rb);
+                    }
+                }
+                op[base_a + o] = ra;
+                if (two) op[base_b + o] = rb;
+            } else {
+                float* op = (float*)out;
+                float ra = v[e].x, rb = v[e].y;
+                if (skip) {
+                    ra = __fadd_rn(__fadd_rn(ld<false>(skip, base_a + o), ld<false>(hres, base_a + o)), ra);
+                    if (two) rb = __fadd_rn(__fadd_rn(ld<false>(skip, base_b + o), ld<false>(hres, base_b + o)), rb);
+                }
+                op[base_a + o] = ra;
+                if (two) op[base_b + o] = rb;
+            }
+        }
+    }
+}
+
+template <int H, int W, bool BF16>
+int launch_hf(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int radius,
+              hipStream_t stream) {
+    const size_t lds = (size_t)(64 + H * (W + 1)) * sizeof(float2);
+    auto kern = hf_kernel<H, W, BF16>;
+    if (lds > 48 * 1024) {
+        static bool done = false;
+        if (!done) {
+            SID_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
+    const int pairs = (C + 1) / 2;
+    hipLaunchKernelGGL(kern, dim3(B * pairs), dim3(256), lds, stream, hcnt, skip, hres, out, C, pairs,
+                       radius * radius);
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}
+
+template <bool BF16>
+int dispatch_hf(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int H, int W,
+                int radius, hipStream_t stream) {
+#define SID_HF(h, w) if (H == h && W == w) return launch_hf<h, w, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
+#define SID_HF_ROW(h) SID_HF(h, 8) SID_HF(h, 16) SID_HF(h, 32) SID_HF(h, 64) SID_HF(h, 128)
+    SID_HF_ROW(8) SID_HF_ROW(16) SID_HF_ROW(32) SID_HF_ROW(64) SID_HF_ROW(128)
+#undef SID_HF_ROW
+#undef SID_HF
+    return sid::fail(SID_ENOSYS, "feature map %dx%d: H and W must be powers of two in [8,128]", H, W);
+}
+
+int hf_common(const void* h_cnt, const void* skip, const void* h, void* out, int B, int C, int H, int W, int radius,
+              int dtype, void* stream) {
+    SID_CHECK_ARG(h_cnt && out, "NULL tensor pointer");
+    SID_CHECK_ARG((skip == nullptr) == (h == nullptr), "skip and h must both be given or both be NULL");
+    SID_CHECK_ARG(B >= 1 && C >= 1, "B and C must be >= 1");
+    SID_CHECK_ARG(radius >= 0, "radius must be >= 0");
+    SID_CHECK_ARG(dtype == SID_DTYPE_F32 || dtype == SID_DTYPE_BF16, "unknown dtype %d", dtype);
+    SID_CHECK_ARG((long long)B * ((C + 1) / 2) < (1LL << 31), "too many feature maps");
+    if (dtype == SID_DTYPE_BF16) return dispatch_hf<true>(h_cnt, skip, h, out, B, C, H, W, radius, (hipStream_t)stream);
+    return dispatch_hf<false>(h_cnt, skip, h, out, B, C, H, W, radius, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" int sid_hf_filter_radius(const void* h_cnt, const void* skip, const void* h, void* out, int B, int C,
+                                    int H, int W, int radius, int dtype, void* stream) {
+    return hf_common(h_cnt, skip, h, out, B, C, H, W, radius, dtype, stream);
+}
+
+extern "C" int sid_hf_filter(const void* h_cnt, const void* skip, const void* h, void* out, int B, int C, int H,
+                             int W, float ratio, int dtype, void* stream) {
+    SID_CHECK_ARG(std::isfinite(ratio) && ratio >= 0.f, "ratio must be finite and >= 0 (got %g)", (double)ratio);
+    SID_CHECK_ARG(H >= 1 && W >= 1, "H and W must be >= 1");
+    // int(min(H, W) * radius_ratio), truncation toward zero
+    const int radius = (int)((double)std::min(H, W) * (double)ratio);
+    return hf_common(h_cnt, skip, h, out, B, C, H, W, radius, dtype, stream);
+}

@@ -1,0 +1,156 @@
+"""Tensor-level entry points: torch device tensors in, HIP kernels enqueued on the current stream.
+
+PyTorch is used for device memory and streams only; all arithmetic of the path happens in
+libsid.so.  Every function raises if the library is missing or rejects the call.
+"""
+import torch
+
+from . import lib as _lib
+
+_workspaces = {}
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.DTYPE_BF16
+    raise TypeError("tensors must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _compute_code(compute):
+    if compute in ("bf16", _lib.COMPUTE_BF16):
+        return _lib.COMPUTE_BF16
+    if compute in ("fp32", "f32", "f32x3", _lib.COMPUTE_F32X3):
+        return _lib.COMPUTE_F32X3
+    raise ValueError("compute must be 'bf16' or 'fp32', got %r" % (compute,))
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(device, nbytes):
+    """One growing scratch buffer per (device, stream): calls on one stream run in order, so
+    they can share it; allocation happens here, never inside the library."""
+    key = (device.index, _stream(device))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _need_cuda(*ts):
+    dev = ts[0].device
+    for t in ts:
+        if t.device.type != "cuda":
+            raise RuntimeError("libsid kernels need tensors in GPU memory (got %s)" % t.device)
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+        if not t.is_contiguous():
+            raise RuntimeError("tensors must be contiguous")
+    return dev
+
+
+def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, gamma, T, scale,
+                       heads, q_self_coef=0.5, compute="bf16", out=None):
+    """x_q (B,N,H*d); q_cnt,k*,v* (B*H,N,d); mask_signed (B,N) or (N,) float32 -> (B,N,H*d)."""
+    L = _lib.load()
+    B, N, C = x_q.shape
+    H = heads
+    d = C // H
+    ts = (x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt)
+    dev = _need_cuda(*ts, mask_signed)
+    for t in ts[1:]:
+        if tuple(t.shape) != (B * H, N, d):
+            raise ValueError("feature tensors must be (B*H, N, d) = %s, got %s" % ((B * H, N, d), tuple(t.shape)))
+        if t.dtype != x_q.dtype:
+            raise TypeError("all attention tensors must share one dtype")
+    if mask_signed.dtype != torch.float32 or mask_signed.numel() != B * N:
+        raise ValueError("mask_signed must be float32 with B*N elements")
+    dt = _dtype_code(x_q)
+    cc = _compute_code(compute)
+    if out is None:
+        out = torch.empty((B, N, C), dtype=x_q.dtype, device=dev)
+    nbytes = L.sid_injected_attn_workspace_bytes(B, H, N, d, cc)
+    if nbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_injected_attn_fwd(
+            x_q.data_ptr(), q_cnt.data_ptr(), k1.data_ptr(), v1.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+            k_cnt.data_ptr(), v_cnt.data_ptr(), mask_signed.data_ptr(), out.data_ptr(),
+            B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale), dt, cc, 0,
+            ws.data_ptr(), ws.numel(), _stream(dev)))
+    return out
+
+
+def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="bf16", out=None):
+    """softmax((q k^T) * logit_scale) v.  Layout 'bnhd': (B,N,H*d); 'bhnd': (B*H,N,d).
+    Returns (B, Nq, H*d)."""
+    L = _lib.load()
+    H = heads
+    lay = {"bnhd": _lib.LAYOUT_BNHD, "bhnd": _lib.LAYOUT_BHND}
+    dev = _need_cuda(q, k, v)
+
+    def dims(t, layout):
+        if layout == "bnhd":
+            b, n, c = t.shape
+            return b, n, c // H
+        bh, n, d_ = t.shape
+        return bh // H, n, d_
+
+    B, Nq, d = dims(q, q_layout)
+    Bk, Nk, dk = dims(k, kv_layout)
+    if (Bk, dk) != (B, d) or tuple(v.shape) != tuple(k.shape):
+        raise ValueError("q/k/v shapes disagree: %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(v.shape)))
+    if not (q.dtype == k.dtype == v.dtype):
+        raise TypeError("q, k, v must share one dtype")
+    dt = _dtype_code(q)
+    cc = _compute_code(compute)
+    if out is None:
+        out = torch.empty((B, Nq, H * d), dtype=q.dtype, device=dev)
+    nbytes = L.sid_plain_attn_workspace_bytes(B, H, Nq, Nk, d, cc)
+    if nbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_plain_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk, d,
+                                        float(logit_scale), lay[q_layout], lay[kv_layout], dt, cc, 0,
+                                        ws.data_ptr(), ws.numel(), _stream(dev)))
+    return out
+
+
+def mask_downsample(mask, out_h, out_w, ch=1.0):
+    """(Hin, Win) float32 mask in [0,1] on the GPU -> signed (out_h*out_w,) float32."""
+    L = _lib.load()
+    dev = _need_cuda(mask)
+    if mask.dtype != torch.float32 or mask.dim() != 2:
+        raise ValueError("mask must be a 2-D float32 tensor")
+    out = torch.empty(out_h * out_w, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_mask_downsample(mask.data_ptr(), mask.shape[0], mask.shape[1], out_h, out_w, float(ch),
+                                         out.data_ptr(), _stream(dev)))
+    return out
+
+
+def hf_filter(h_cnt, ratio=0.5, skip=None, h=None, out=None):
+    """HF(h_cnt), or skip + h + HF(h_cnt) when skip and h are given.  (B,C,H,W) tensors."""
+    L = _lib.load()
+    ts = [h_cnt] + ([skip, h] if skip is not None else [])
+    dev = _need_cuda(*ts)
+    if (skip is None) != (h is None):
+        raise ValueError("skip and h must be given together")
+    for t in ts:
+        if t.shape != h_cnt.shape or t.dtype != h_cnt.dtype:
+            raise ValueError("skip, h and h_cnt must share shape and dtype")
+    B, C, Hh, Ww = h_cnt.shape
+    radius = int(min(Hh, Ww) * ratio)          # high_frequency_final.py:18, in double like the reference
+    if out is None:
+        out = torch.empty_like(h_cnt)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_hf_filter_radius(h_cnt.data_ptr(), skip.data_ptr() if skip is not None else None,
+                                          h.data_ptr() if h is not None else None, out.data_ptr(),
+                                          B, C, Hh, Ww, radius, _dtype_code(h_cnt), _stream(dev)))
+    return out
