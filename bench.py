@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: stylised images per second on the injection path of one 512x512 image.
+
+A step is the hot path of ONE stylised image (50 DDIM steps = 49 UNet evaluations): per
+evaluation 6 injected three-block attentions (3 x N=4096,d=40 and 3 x N=1024,d=80), the 10
+non-injected self-attentions of the UNet (7 plain, 3 temperature-scaled), and, on the 20
+scheduled evaluations, the fused high-frequency filter of the 6 decoder ResBlocks
+(3 x (640,32,32), 3 x (320,64,64)).  The convolutions, GroupNorms, cross-attention, VAE and
+sampler arithmetic of the UNet are NOT part of the path and are not run.  Inputs are synthetic
+(seeded normal), already resident in HBM; every evaluation reads its own feature tensors, as
+the precomputed feature lists do.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints one JSON line on rank 0.  For N > 1 launch with torch.distributed.run; every rank
+stylises its own images (the path shards over images, no data-path collective) and rank 0
+gathers the output latents once at the end over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from style_transfer_amd import lib as sid_lib  # noqa: E402
+from style_transfer_amd import ops  # noqa: E402
+
+HEADS = 8
+GAMMA, TEMP, RATIO = 0.5, 1.5, 0.5
+EVALS = 49
+HF_EVALS = 20                     # int(0.4 * 50) scheduled timesteps
+INJECTED = [(1024, 80)] * 3 + [(4096, 40)] * 3            # output blocks 6-8, 9-11
+PLAIN = [(4096, 40, 1.0)] * 2 + [(1024, 80, 1.0)] * 2 + [(256, 160, 1.0)] * 2 + [(64, 160, 1.0)] + \
+        [(256, 160, TEMP)] * 3                            # input 1,2,4,5,7,8; middle; output 3,4,5 (T)
+HF_MAPS = [(640, 32)] * 3 + [(320, 64)] * 3
+MFMA_PEAK = 2.5e15                # dense bf16 MFMA, FLOP/s (MI355X spec)
+HBM_PEAK = 8.0e12
+
+
+def make_image_workload(dev, gen, dtype):
+    """All tensors one image's hot path reads, resident on `dev`."""
+    def rn(*shape):
+        return torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dtype)
+
+    w = {"inj": [], "plain": [], "hf": []}
+    for (N, d) in INJECTED:
+        layer = {"N": N, "d": d, "xq": rn(1, N, HEADS * d), "feats": []}
+        for _ in range(EVALS):
+            layer["feats"].append([rn(HEADS, N, d) for _ in range(7)])   # q_cnt k1 v1 k2 v2 k_cnt v_cnt
+        side = int(N ** 0.5)
+        yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
+        disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
+        layer["mask"] = ops.mask_downsample(disc, side, side, 1.0)
+        w["inj"].append(layer)
+    for (N, d, T) in PLAIN:
+        w["plain"].append({"N": N, "d": d, "T": T, "q": rn(1, N, HEADS * d), "k": rn(1, N, HEADS * d),
+                           "v": rn(1, N, HEADS * d)})
+    for (C, S) in HF_MAPS:
+        w["hf"].append({"h_cnt": [rn(1, C, S, S) for _ in range(HF_EVALS)], "skip": rn(1, C, S, S), "h": rn(1, C, S, S)})
+    return w
+
+
+def run_image(w, compute):
+    """The hot path of one image: 49 evaluations in UNet order."""
+    outs = None
+    for e in range(EVALS):
+        for p in w["plain"][:7]:
+            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute)
+        for p in w["plain"][7:]:
+            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute)
+        hf_on = e >= EVALS - HF_EVALS          # the 20 smallest timesteps come last
+        for li, layer in enumerate(w["inj"]):
+            if hf_on:
+                m = w["hf"][li]
+                ops.hf_filter(m["h_cnt"][e - (EVALS - HF_EVALS)], RATIO, skip=m["skip"], h=m["h"])
+            f = layer["feats"][e]
+            outs = ops.injected_attention(layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"],
+                                          GAMMA, TEMP, layer["d"] ** -0.5, HEADS, compute=compute)
+    return outs
+
+
+def flash_kernel_time(w, compute, reps=50):
+    """Average duration of the dominant kernel (the flash stage at N=4096, d=40), HIP events on
+    the launch stream around `reps` back-to-back launches."""
+    layer = w["inj"][-1]
+    f = layer["feats"][0]
+    args = (layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"], GAMMA, TEMP, layer["d"] ** -0.5, HEADS)
+    ops.injected_attention(*args, compute=compute)                      # full call fills the workspace
+    for _ in range(5):
+        ops.injected_attention(*args, compute=compute, flags=0x20)      # flash stage only
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        ops.injected_attention(*args, compute=compute, flags=0x20)
+    ev1.record()
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The C oracle (oracle/, a port of the reference arithmetic) timed on this host's cores on a
+    bounded sample of query rows / feature maps of the same workload, scaled to one image."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sid_oracle_c as oc
+    rng = np.random.default_rng(0)
+    per_image = 0.0
+    sample = []
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    for (N, d), count in (((4096, 40), 3), ((1024, 80), 3)):
+        rows = 512 if N == 4096 else 256
+        a = [rng.standard_normal((1, N, HEADS * d), dtype=np.float32)[0]] + \
+            [rng.standard_normal((HEADS, N, d), dtype=np.float32) for _ in range(7)]
+        m = np.sign(rng.standard_normal(N)).astype(np.float32)
+        oc.injected_attention_rows(0, 16, *a, m, GAMMA, TEMP, d ** -0.5)
+        t = timed(lambda: oc.injected_attention_rows(0, rows, *a, m, GAMMA, TEMP, d ** -0.5))
+        per_image += EVALS * count * t * N / rows
+        sample.append("injected N=%d d=%d: %d of %d rows" % (N, d, rows, N))
+    for (N, d, T) in sorted(set(PLAIN)):
+        count = PLAIN.count((N, d, T))
+        rows = min(N, 256)
+        q, k, v = (rng.standard_normal((HEADS, N, d), dtype=np.float32) for _ in range(3))
+        t = timed(lambda: oc.plain_attention_rows(0, rows, q, k, v, d ** -0.5, T))
+        per_image += EVALS * count * t * N / rows
+    sample.append("plain self-attention: <=256 rows per shape")
+    for (C, S) in sorted(set(HF_MAPS)):
+        maps = 64
+        x, s, h = (rng.standard_normal((1, maps, S, S), dtype=np.float32) for _ in range(3))
+        t = timed(lambda: oc.hf_filter(x, RATIO, s, h))
+        per_image += HF_EVALS * 3 * t * C / maps
+    sample.append("HF filter: 64 maps per shape")
+    return {"value": 1.0 / per_image, "unit": "imgs/s", "cores": oc.threads(), "kind": "port",
+            "sample": "; ".join(sample) + "; scaled to 49 evaluations of one image"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the feature tensors")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the path has no CPU fallback)")
+    sid_lib.load()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    dtype = torch.float32 if args.io == "f32" else torch.bfloat16
+    w = make_image_workload(dev, gen, dtype)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_image(w, args.compute)
+    barrier()
+    t0 = time.perf_counter()
+    latents = []
+    for _ in range(args.steps):
+        out = run_image(w, args.compute)
+        latents.append(out.reshape(-1)[:4 * 64 * 64].clone())   # stand-in for the (1,4,64,64) latent, 64 KiB
+    mine = torch.stack(latents).float()
+    if dist is not None:                                   # the one collective of the job
+        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        t_flash = flash_kernel_time(w, args.compute)
+        flops = 12.0 * 1 * HEADS * 4096 ** 2 * 40           # 3 QK^T + 3 PV blocks, d = 40 (no padding counted)
+        achieved = flops / t_flash
+        line = {
+            "metric": "stylized imgs/sec (512^2, 50 DDIM), injection hot path",
+            "value": world * args.steps / elapsed,
+            "unit": "imgs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "bf16x3 (f32-grade)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: one content + char/back style pair, 512^2, gamma=0.5 T=1.5 ratio=0.5, "
+                                   "49 UNet evaluations: 6 injected + 10 self attention calls each, fused HF filter "
+                                   "on 6 ResBlocks for 20 evaluations; hot path only (UNet convs/VAE not run)",
+                       "feature_storage": args.io, "images_per_rank": args.steps,
+                       "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "flash_kernel<3,2> injected attention N=4096 d=40 H=8 B=1",
+                         "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK, "traffic": None, "kernel_ms": t_flash * 1e3,
+                         "algorithmic_flop": flops},
+            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,12 @@ extern "C" {
 
 /* flags (bit mask) */
 #define SID_FLAG_BLOCK_SKIP 1 /* reserved: skip key blocks whose weight underflows f32 */
+/* Stage selection for measurement: an attention call is pack -> flash -> merge.  With none of
+ * these bits set all three run.  A call that leaves out an earlier stage reuses what a previous
+ * call with the same shape arguments left in the same workspace. */
+#define SID_FLAG_STAGE_PACK 0x10
+#define SID_FLAG_STAGE_FLASH 0x20
+#define SID_FLAG_STAGE_MERGE 0x40
 
 const char* sid_last_error(void);
 int sid_version(void);

@@ -633,6 +633,16 @@ int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream) {
     return SID_OK;
 }
 
+struct Stages {
+    bool pack, flash, merge;
+    explicit Stages(int flags) {
+        const int sel = flags & (SID_FLAG_STAGE_PACK | SID_FLAG_STAGE_FLASH | SID_FLAG_STAGE_MERGE);
+        pack = sel == 0 || (sel & SID_FLAG_STAGE_PACK);
+        flash = sel == 0 || (sel & SID_FLAG_STAGE_FLASH);
+        merge = sel == 0 || (sel & SID_FLAG_STAGE_MERGE);
+    }
+};
+
 int check_common(int B, int H, int Nq, int Nk, int d, int dtype, int compute) {
     SID_CHECK_ARG(B >= 1 && H >= 1 && Nq >= 1 && Nk >= 1, "B,H,N must be >= 1 (got B=%d H=%d Nq=%d Nk=%d)", B, H, Nq, Nk);
     SID_CHECK_ARG(d >= 1 && d <= 160, "head_dim %d out of range [1,160]", d);
@@ -659,8 +669,8 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
                                      float gamma, float q_self_coef, float T, float scale, int dtype,
                                      int compute, int flags, void* workspace, size_t workspace_bytes,
                                      void* stream_) {
-    (void)flags;
     hipStream_t stream = (hipStream_t)stream_;
+    const Stages stg(flags);
     int rc = check_common(B, H, N, N, d, dtype, compute);
     if (rc != SID_OK) return rc;
     SID_CHECK_ARG(x_q && q_cnt && k1 && v1 && k2 && v2 && k_cnt && v_cnt && mask_signed && out, "NULL tensor pointer");
@@ -699,8 +709,10 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
         rowjob(5 + b, vs[b], w.v[b][0], w.v[b][1], g.NKT, g.v_units);
         pp.job[5 + b].kind = 1;
     }
-    rc = launch_pack(pp, frags, stream);
-    if (rc != SID_OK) return rc;
+    if (stg.pack) {
+        rc = launch_pack(pp, frags, stream);
+        if (rc != SID_OK) return rc;
+    }
 
     // ---- flash
     constexpr float LOG2E = 1.4426950408889634f;
@@ -716,8 +728,11 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     fp.opart = w.opart; fp.stats = w.stats;
     fp.BH = B * H; fp.Nq = N; fp.Nk = N; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
     fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = kBlocks;
-    rc = x3 ? launch_flash<true>(fp, g, stream) : launch_flash<false>(fp, g, stream);
-    if (rc != SID_OK) return rc;
+    if (stg.flash) {
+        rc = x3 ? launch_flash<true>(fp, g, stream) : launch_flash<false>(fp, g, stream);
+        if (rc != SID_OK) return rc;
+    }
+    if (!stg.merge) return SID_OK;
 
     // ---- merge
     MergeParams mp = {};
@@ -746,8 +761,8 @@ extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, i
 extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq,
                                   int Nk, int d, float logit_scale, int q_layout, int kv_layout, int dtype,
                                   int compute, int flags, void* workspace, size_t workspace_bytes, void* stream_) {
-    (void)flags;
     hipStream_t stream = (hipStream_t)stream_;
+    const Stages stg(flags);
     int rc = check_common(B, H, Nq, Nk, d, dtype, compute);
     if (rc != SID_OK) return rc;
     SID_CHECK_ARG(q && k && v && out, "NULL tensor pointer");
@@ -778,8 +793,10 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     job(0, q, w.q[0][0], w.q[0][1], 0, Nq, g.NQT, g.q_units, q_layout);
     job(1, k, w.k[0][0], w.k[0][1], 0, Nk, g.NKT, g.k_units, kv_layout);
     job(2, v, w.v[0][0], w.v[0][1], 1, Nk, g.NKT, g.v_units, kv_layout);
-    rc = launch_pack(pp, frags, stream);
-    if (rc != SID_OK) return rc;
+    if (stg.pack) {
+        rc = launch_pack(pp, frags, stream);
+        if (rc != SID_OK) return rc;
+    }
 
     constexpr float LOG2E = 1.4426950408889634f;
     FlashParams fp = {};
@@ -790,8 +807,11 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     fp.opart = w.opart; fp.stats = w.stats;
     fp.BH = B * H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
     fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = 1;
-    rc = x3 ? launch_flash<true>(fp, g, stream) : launch_flash<false>(fp, g, stream);
-    if (rc != SID_OK) return rc;
+    if (stg.flash) {
+        rc = x3 ? launch_flash<true>(fp, g, stream) : launch_flash<false>(fp, g, stream);
+        if (rc != SID_OK) return rc;
+    }
+    if (!stg.merge) return SID_OK;
 
     MergeParams mp = {};
     mp.opart = w.opart; mp.stats = w.stats; mp.mask = nullptr; mp.out = out; mp.scale = 1.f;

@@ -1,0 +1,38 @@
+"""Feature-list layout of the precomputed DDIM-inversion features and their merge.
+
+A feature file (`precomputed_feats_k/<name>_cnt.pkl` / `<name>_sty.pkl`) is a list of 50 dicts,
+index i <-> timestep 981 - 20*i, each with 'config', 'z_enc' and 18 tensors
+`output_block_{6..11}_self_attn_{q,k,v}` of shape (8, N, d) (generate_pkl_only.py:101-142).
+"""
+
+NUM_STEPS = 50
+
+
+def feat_merge_2sty(opt, cnt_feats, sty_feats_1, sty_feats_2, start_step=0):
+    """Re-key three feature lists into the per-step dicts the UNet consumes (run_ori.py:36-75).
+
+    For every step i >= 50 - start_step and every key K of the content dict:
+      K ending in 'q'        -> out[K] = content;  out[K+'_sty1'] = char;  out[K+'_sty2'] = back
+      K ending in 'k' / 'v'  -> out[K] = char;     out[K+'_cnt'] = content; out[K+'_sty2'] = back
+    Tensors are referenced, never copied.  Every step dict carries
+    'config' = {'gamma', 'T', 'timestep': i, 'cnt_k': None, 'sty_q': None}.
+    """
+    merged = [{'config': {'gamma': opt.gamma, 'T': opt.T, 'timestep': i, 'cnt_k': None, 'sty_q': None}}
+              for i in range(NUM_STEPS)]
+    for i in range(NUM_STEPS):
+        if i < (NUM_STEPS - start_step):
+            continue
+        cnt, sty1, sty2 = cnt_feats[i], sty_feats_1[i], sty_feats_2[i]
+        step = merged[i]
+        for key in cnt.keys():
+            is_q = key.endswith('q')
+            is_kv = key.endswith('k') or key.endswith('v')
+            if is_q:
+                step[key] = cnt[key]
+                step[key + '_sty1'] = sty1[key]
+            if is_kv:
+                step[key] = sty1[key]
+                step[key + '_cnt'] = cnt[key]
+            if is_q or is_kv:
+                step[key + '_sty2'] = sty2[key]
+    return merged

@@ -54,7 +54,7 @@ def _need_cuda(*ts):
 
 
 def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, gamma, T, scale,
-                       heads, q_self_coef=0.5, compute="bf16", out=None):
+                       heads, q_self_coef=0.5, compute="bf16", out=None, flags=0):
     """x_q (B,N,H*d); q_cnt,k*,v* (B*H,N,d); mask_signed (B,N) or (N,) float32 -> (B,N,H*d)."""
     L = _lib.load()
     B, N, C = x_q.shape
@@ -81,7 +81,7 @@ def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, ga
         _lib.check(L.sid_injected_attn_fwd(
             x_q.data_ptr(), q_cnt.data_ptr(), k1.data_ptr(), v1.data_ptr(), k2.data_ptr(), v2.data_ptr(),
             k_cnt.data_ptr(), v_cnt.data_ptr(), mask_signed.data_ptr(), out.data_ptr(),
-            B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale), dt, cc, 0,
+            B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale), dt, cc, int(flags),
             ws.data_ptr(), ws.numel(), _stream(dev)))
     return out
 

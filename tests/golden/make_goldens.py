@@ -237,8 +237,33 @@ def gen_hf():
     print("hf:", len(cases), "cases")
 
 
+def gen_feat_merge():
+    """run_ori.py cannot be imported here (omegaconf / pytorch_lightning are absent), so only its
+    function `feat_merge_2sty` is compiled from the file's syntax tree and run on tagged
+    placeholder 'tensors'; the fixture records which source each output key refers to."""
+    import ast
+    import types
+    src = open(os.path.join(REF, "run_ori.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "feat_merge_2sty"][0]
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "run_ori.py", "exec"), ns)
+    keys = ["z_enc", "config"] + [f"output_block_{b}_self_attn_{t}" for b in range(6, 12) for t in "qkv"]
+    mk = lambda tag: [{k: f"{tag}[{i}].{k}" for k in keys} for i in range(50)]
+    opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+    out = {}
+    for start_step in (49, 30, 50, 0):
+        merged = ns["feat_merge_2sty"](opt, mk("cnt"), mk("char"), mk("back"), start_step=start_step)
+        out[str(start_step)] = merged
+    with open(os.path.join(HERE, "feat_merge.json"), "w") as f:
+        json.dump(out, f)
+    print("feat_merge: steps", {k: sum(len(d) > 1 for d in v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "hf", "attention"]
+    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge"]
+    if "feat_merge" in which:
+        gen_feat_merge()
     if "masks" in which:
         gen_masks()
     if "hf" in which:

@@ -138,3 +138,65 @@ def test_hf_filter_fused_residual_and_odd_channels():
         got = ops.hf_filter(g(h), ratio, skip=g(s), h=g(r)).cpu().numpy()
         want = orc.resblock_hf_merge(s, r, h, ratio)
         assert rel_err(got, want) < 1e-5, shape
+
+
+MODULE_CASES = [c for c in attention_cases() if c.get("module_weights")]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", MODULE_CASES, ids=lambda c: f"{c['id']}-{c['branch']}")
+def test_cross_attention_module_drop_in(case, compute, tmp_path):
+    """The drop-in class end to end (to_q -> kernels -> to_out) against the reference module run
+    with the same seeded weights, mask file and keywords."""
+    from helpers import module_weights
+    from style_transfer_amd.attention import CrossAttention
+    gold = attention_golden()
+    H, d = case["heads"], case["d"]
+    w = module_weights(case)
+    mod = CrossAttention(query_dim=H * d, heads=H, dim_head=d).to(dev())
+    with torch.no_grad():
+        mod.to_q.weight.copy_(g(w["to_q"]))
+        mod.to_k.weight.copy_(g(w["to_k"]))
+        mod.to_v.weight.copy_(g(w["to_v"]))
+        mod.to_out[0].weight.copy_(g(w["to_out_w"]))
+        mod.to_out[0].bias.copy_(g(w["to_out_b"]))
+    mod.compute = compute
+    np.save(str(tmp_path / "img_mask.npy"), mask_for(case["mask"]))
+    mod.cnt_name = str(tmp_path / "img.jpg")
+    t = {k: g(v) for k, v in case_inputs(case).items()}
+    cfg = {"T": case["T"], "gamma": case["gamma"]}
+    with torch.no_grad():
+        if case["branch"] == "injected":
+            out = mod(t["xq"], q_injected=t["q_cnt"], k_injected=t["k1"], v_injected=t["v1"],
+                      cnt_k_injected=t["k_cnt"], sty_q_injected=None, cnt_v_injected=t["v_cnt"],
+                      sty2_q_injected=None, sty2_k_injected=t["k2"], sty2_v_injected=t["v2"], injection_config=cfg)
+            # attributes the reference leaves on the module (attention.py:404-406)
+            assert mod.k is t["k1"] or torch.equal(mod.k, t["k1"])
+            q_ref = orc.blend_query((t["xq"][0] @ mod.to_q.weight.T).cpu().numpy(), t["q_cnt"].cpu().numpy(), case["gamma"])
+            assert rel_err(mod.q.cpu().numpy(), q_ref) < 1e-5
+        else:
+            out = mod(t["xq"], injection_config=cfg)
+    out = out[0].cpu().numpy()
+    rows = np.array(case["rows"])
+    assert rel_err(out[rows], gold[f"out_rows/{case['id']}"]) < TOL[compute]
+    check_sums(out, gold, case, TOL[compute])
+
+
+def test_gen_pkl_mode_exposes_features():
+    """Feature-extraction mode keeps q/k/v/qk_sim on the module (generate_pkl_only.py:128-130 reads them)."""
+    from style_transfer_amd.attention import CrossAttention
+    case = [c for c in attention_cases() if c["branch"] == "genpkl"][0]
+    gold = attention_golden()
+    H, d, N = case["heads"], case["d"], case["N"]
+    mod = CrossAttention(query_dim=H * d, heads=H, dim_head=d).to(dev())
+    eye = torch.eye(H * d, device=dev())
+    with torch.no_grad():
+        for lin in (mod.to_q, mod.to_k, mod.to_v, mod.to_out[0]):
+            lin.weight.copy_(eye)
+        mod.to_out[0].bias.zero_()
+    mod.gen_pkl = True
+    x = g(case_inputs(case)["xq"])
+    with torch.no_grad():
+        out = mod(x)[0].cpu().numpy()
+    assert rel_err(out[np.array(case["rows"])], gold[f"out_rows/{case['id']}"]) < 1e-4
+    assert tuple(mod.q.shape) == (H, N, d) and tuple(mod.qk_sim.shape) == (H, N, N) and mod.attn is not None

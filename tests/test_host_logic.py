@@ -1,0 +1,95 @@
+"""Host-side logic and the C ABI surface (no GPU, no compute calls)."""
+import ctypes
+import json
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, hf_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_feat_merge_2sty_matches_reference():
+    from style_transfer_amd.features import feat_merge_2sty
+    with open(os.path.join(GOLDEN, "feat_merge.json")) as f:
+        gold = json.load(f)
+    keys = ["z_enc", "config"] + [f"output_block_{b}_self_attn_{t}" for b in range(6, 12) for t in "qkv"]
+    mk = lambda tag: [{k: f"{tag}[{i}].{k}" for k in keys} for i in range(50)]
+    opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+    for start_step, want in gold.items():
+        got = feat_merge_2sty(opt, mk("cnt"), mk("char"), mk("back"), start_step=int(start_step))
+        assert got == want, start_step
+    # step 0 is skipped at the default start_step=49 and the UNet-facing keys exist from step 1
+    got = feat_merge_2sty(opt, mk("cnt"), mk("char"), mk("back"), start_step=49)
+    assert list(got[0].keys()) == ["config"]
+    assert got[1]["output_block_9_self_attn_k_cnt"] == "cnt[1].output_block_9_self_attn_k"
+    assert got[1]["output_block_9_self_attn_k"] == "char[1].output_block_9_self_attn_k"
+    assert got[1]["output_block_9_self_attn_v_sty2"] == "back[1].output_block_9_self_attn_v"
+
+
+def test_schedule_matches_reference():
+    from style_transfer_amd.high_frequency import make_content_injection_schedule
+    misc = hf_cases()
+    ts = np.array(misc["ddim_timesteps_50"])
+    assert [int(t) for t in make_content_injection_schedule(ts)] == misc["content_injection_schedule_50"]
+    assert [int(t) for t in make_content_injection_schedule(ts, 0.25)] == misc["content_injection_schedule_50_a25"]
+
+
+def test_library_exports_every_declared_symbol():
+    from style_transfer_amd import lib
+    header = open(os.path.join(ROOT, "include", "sid.h")).read()
+    declared = set(re.findall(r"\b(sid_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    L = lib.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sid_version() == 100
+
+
+def test_argument_checks_reject_without_a_gpu():
+    """Validation happens before any HIP call, so it can be exercised on a CPU-only host."""
+    from style_transfer_amd import lib
+    L = lib.load()
+    assert L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, 0) > 0
+    assert L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, 1) > L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, 0)
+    assert L.sid_injected_attn_workspace_bytes(1, 8, 4096, 400, 0) == 0
+    assert b"head_dim" in L.sid_last_error()
+    rc = L.sid_injected_attn_fwd(*([None] * 10), 1, 8, 64, 40, 0.5, 0.5, 1.5, 0.1, 0, 0, 0, None, 0, None)
+    assert rc == -22 and b"NULL" in L.sid_last_error()
+    rc = L.sid_plain_attn_fwd(None, None, None, None, 1, 8, 0, 64, 40, 0.1, 0, 0, 0, 0, 0, None, 0, None)
+    assert rc == -22
+    rc = L.sid_hf_filter(None, None, None, None, 1, 4, 64, 64, 0.5, 0, None)
+    assert rc == -22
+    buf = ctypes.create_string_buffer(16)
+    rc = L.sid_hf_filter(buf, None, None, buf, 1, 4, 48, 64, 0.5, 0, None)     # 48 is not a power of two
+    assert rc == -38 and b"powers of two" in L.sid_last_error()
+    rc = L.sid_mask_downsample(buf, 512, 512, 64, 64, 2.0, buf, None)
+    assert rc == -22 and b"ch must be" in L.sid_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from style_transfer_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsid.so")
+    with pytest.raises(ImportError, match="no fallback"):
+        lib.load()
+
+
+def test_cross_attention_shim_signature_matches_reference():
+    import inspect
+    from style_transfer_amd.attention import CrossAttention
+    want = ["self", "x", "context", "mask", "q_injected", "k_injected", "v_injected", "cnt_k_injected",
+            "sty_q_injected", "cnt_v_injected", "sty2_q_injected", "sty2_k_injected", "sty2_v_injected",
+            "injection_config"]
+    assert list(inspect.signature(CrossAttention.forward).parameters) == want
+    m = CrossAttention(query_dim=320, heads=8, dim_head=40)
+    assert m.scale == 40 ** -0.5 and m.heads == 8 and m.gen_pkl is False and m.cnt_name is None
+    assert set(dict(m.named_parameters())) == {"to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight",
+                                               "to_out.0.bias"}
+    import torch
+    with pytest.raises(TypeError):                       # cnt_name=None fails like the reference does
+        m(torch.zeros(1, 64, 320))
