@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsid.so")
+LIB_PATH = os.environ.get("SID_LIB_OVERRIDE") or os.path.join(HERE, "libsid.so")   # override: kernel experiments only
 
 SID_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1

@@ -1,7 +1,7 @@
 """Print per-kernel register/LDS/scratch usage of a HIP source (gfx950)."""
 import re, subprocess, sys
 src = sys.argv[1]
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c", src,
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", src,
                     "-o", "/tmp/_ru.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:], capture_output=True, text=True)
 cur = None
 rows = {}
