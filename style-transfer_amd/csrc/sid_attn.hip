@@ -1,24 +1,27 @@
 // Injected three-block attention and single-block attention for gfx950 (MI355X).
 //
-// Two kernels per call, both on the caller's stream:
+// Up to three kernels per call, all on the caller's stream:
 //   1. pack   : f32/bf16 inputs -> bf16 MFMA operand fragments in the workspace.  The query blend
 //               q = q_cnt*gamma + x_q*coef happens here; K is zero-padded to a multiple of 16 in
 //               head_dim; V gets a column of ones (so P*V also yields the softmax row sums) and is
 //               stored transposed in fragment order.  The fragment image of a 32-key tile is
 //               exactly what a wave's lanes read, so the main kernel copies it to LDS verbatim
 //               and reads it back with conflict-free lane-linear ds_read_b128.
-//   2. flash  : one workgroup per (head, group of query tiles); inside it one wave per (query tile,
-//               part), a part being a key block or a key range of one.  Each wave runs a
-//               flash-style pass over its keys (sid_attn_kernel.hpp), tracking the raw row max/min
-//               of q.k that the mask bias needs; the parts of a query tile are then combined
-//               through LDS -- turning the statistics into the two bias terms
-//               b = (min_j cc - max_j q.k_b) * (mask*ch_b) -- and the final rows are written.
+//   2. flash  : one workgroup per (head, part, group of query tiles), a part being a key block or
+//               a key range of one.  Each wave runs a flash-style pass over the part's keys
+//               (sid_attn_kernel.hpp) for its query tiles and writes an un-normalised partial
+//               plus the raw row max/min of q.k that the mask bias needs.
+//   3. merge  : per query row, turns the statistics into the two bias terms
+//               b = (min_j cc - max_j q.k_b) * (mask*ch_b) and combines the parts' partials into
+//               the softmax over the concatenated keys.  Skipped when there is a single part
+//               (the flash kernel then writes the final rows itself).
 //
 #include "sid_attn_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -143,52 +146,37 @@ bool supported_dims(int d, int* DKS, int* DVB) {
     return false;
 }
 
-// Decomposition of one call: how many query tiles share a workgroup, how the keys are split, how
-// many tiles a stage holds -- sized so the grid covers the 256 CUs with a few waves per SIMD and
-// the workgroup's double-buffered stages fit the 160 KB LDS.
+// Decomposition of one call: waves per workgroup and key splits -- sized so the grid covers the
+// 256 CUs with about two waves per SIMD while as many queries as possible share each K/V stage.
+// SID_TUNE_NW / SID_TUNE_KS override the choice (measurement only).
 int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, Geometry* g) {
     if (!supported_dims(d, &g->DKS, &g->DVB))
         return sid::fail(SID_ENOSYS, "head_dim %d has no kernel instance (supported: 17-48, 49-64, 65-80, 81-96, 113-128, 145-160)", d);
+    g->KVS = stage_tiles(g->DKS, g->DVB, x3);
+    g->QT = query_tiles(g->DKS, g->DVB, x3);
     g->NQT = (Nq + 31) / 32;
     const int nkt = (Nk + 31) / 32;
-    const size_t tileBytes = (size_t)(g->DKS + 2 * g->DVB) * 1024 * (x3 ? 2 : 1);
-    const int RS = ((d + 3) & ~3) + 4;
-    const long long BH = (long long)B * H;
-
-    int best_kvs = 0, best_nqw = 0, best_ks = 0, best_nbuf = 0;
-    double best_score = -1;
-    for (int nbuf = 2; nbuf >= 1 && best_kvs == 0; --nbuf)
-    for (int kvs = 2; kvs >= 1; --kvs) {
-        const int stages = (nkt + kvs - 1) / kvs;
-        const int maxWaves = max_threads(g->DKS, g->DVB, x3) / 64;
-        for (int nqw = 4; nqw >= 1; nqw >>= 1) {
-            for (int ks = 1; ks <= 8; ++ks) {
-                const int np = nblk * ks;
-                if (np * nqw > maxWaves) break;
-                const int sps = (stages + ks - 1) / ks;
-                if ((long long)(ks - 1) * sps * kvs >= nkt) continue;  // a split without any key
-                const size_t lds = std::max((size_t)np * nbuf * kvs * tileBytes, (size_t)np * nqw * 32 * RS * 4);
-                if (lds + 16 > kLdsBytes) break;
-                const long long wgs = BH * ((g->NQT + nqw - 1) / nqw);
-                const long long waves = wgs * np * nqw;
-                // prefer: all CUs busy, then ~3 waves per SIMD, then K/V sharing (large nqw, kvs), few splits
-                const double cu_fill = std::min(1.0, wgs / 256.0);
-                const double simd_fill = std::min(1.0, waves / 3072.0);
-                const double score = 100 * cu_fill + 50 * simd_fill + 2 * nqw + kvs - 1.5 * ks;
-                if (score > best_score) { best_score = score; best_kvs = kvs; best_nqw = nqw; best_ks = ks; best_nbuf = nbuf; }
-            }
-        }
-    }
-    if (best_kvs == 0) return sid::fail(SID_ENOSYS, "head_dim %d does not fit the LDS in this mode", d);
-    g->KVS = best_kvs; g->NQW = best_nqw; g->KS = best_ks; g->NBUF = best_nbuf;
     const int stages = (nkt + g->KVS - 1) / g->KVS;
-    g->SPS = (stages + g->KS - 1) / g->KS;
-    g->NKT = g->KS * g->SPS * g->KVS;          // every split owns exactly SPS stages; the surplus tiles are zero
-    g->nQG = (g->NQT + g->NQW - 1) / g->NQW;
-    g->threads = nblk * g->KS * g->NQW * 64;
-    g->lds = std::max((size_t)nblk * g->KS * g->NBUF * g->KVS * tileBytes, (size_t)nblk * g->KS * g->NQW * 32 * RS * 4);
+    const long long BH = (long long)B * H;
+    const int qwaves = (g->NQT + g->QT - 1) / g->QT;      // waves that cover the queries of one (head, part)
+
+    // waves per workgroup: as many as there are query waves, up to 4, so each staged K/V tile is
+    // shared by up to 4*QT*32 queries
+    int nw = 4;
+    while (nw > 1 && qwaves < nw) nw >>= 1;
+    if (const char* e = getenv("SID_TUNE_NW")) nw = atoi(e);
+    g->NW = nw;
+    g->nQG = (qwaves + nw - 1) / nw;
+    // key splits: until there are >= 2 workgroups per CU, while every split keeps a few stages
+    int ks = 1;
+    while (ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 4) ++ks;
+    if (const char* e = getenv("SID_TUNE_KS")) ks = atoi(e);
+    g->SPS = (stages + ks - 1) / ks;
+    g->KS = (stages + g->SPS - 1) / g->SPS;               // drop splits that would hold no key
+    g->NKT = g->KS * g->SPS * g->KVS;                     // every split owns exactly SPS stages; surplus tiles are zero
+    g->lds = 2 * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
     g->q_units = (size_t)BH * g->NQT * g->DKS * 64;
-    g->k_units = (size_t)BH * (g->NKT + 1) * g->DKS * 64;        // one zero tile more: QK^T runs a tile ahead
+    g->k_units = (size_t)BH * g->NKT * g->DKS * 64;
     g->v_units = (size_t)BH * g->NKT * 2 * g->DVB * 64;
     return SID_OK;
 }
@@ -197,10 +185,12 @@ struct Workspace {
     u32x4* q[2][2];              // [which: 0 blended, 1 content][part: hi, lo]
     u32x4* k[kBlocks][2];
     u32x4* v[kBlocks][2];
+    float* opart;                // [parts][BH][Nq][d]
+    float* stats;                // [parts][BH][Nq][4]
     size_t bytes;
 };
 
-void carve(const Geometry& g, int nblk, int nq, bool x3, void* base, Workspace* w) {
+void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, void* base, Workspace* w) {
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += sid::align_up(bytes, 256); return p; };
     const int parts = x3 ? 2 : 1;
@@ -209,6 +199,12 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, void* base, Workspace* 
     for (int i = 0; i < nq; ++i) for (int p = 0; p < parts; ++p) w->q[i][p] = (u32x4*)take(g.q_units * 16);
     for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->k[i][p] = (u32x4*)take(g.k_units * 16);
     for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->v[i][p] = (u32x4*)take(g.v_units * 16);
+    const int np = nblk * g.KS;                     // rows = B*H*Nq
+    w->opart = w->stats = nullptr;
+    if (np > 1) {
+        w->opart = (float*)take((size_t)np * rows * d * 4);
+        w->stats = (float*)take((size_t)np * rows * 16);
+    }
     w->bytes = off;
 }
 
@@ -233,11 +229,12 @@ int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream) {
 }
 
 struct Stages {
-    bool pack, flash;
+    bool pack, flash, merge;
     explicit Stages(int flags) {
         const int sel = flags & (SID_FLAG_STAGE_PACK | SID_FLAG_STAGE_FLASH | SID_FLAG_STAGE_MERGE);
         pack = sel == 0 || (sel & SID_FLAG_STAGE_PACK);
-        flash = sel == 0 || (sel & (SID_FLAG_STAGE_FLASH | SID_FLAG_STAGE_MERGE));
+        flash = sel == 0 || (sel & SID_FLAG_STAGE_FLASH);
+        merge = sel == 0 || (sel & SID_FLAG_STAGE_MERGE);
     }
 };
 
@@ -250,6 +247,25 @@ int check_common(int B, int H, int Nq, int Nk, int d, int dtype, int compute) {
     return SID_OK;
 }
 
+// flash + merge stages shared by the two entry points
+int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, const Stages& stg, const float* mask,
+                    void* out, float scale, int B, int H, int Nq, int Nk, int d, int nblk, int dtype, bool x3,
+                    hipStream_t stream) {
+    fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
+    fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
+    fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = nblk; fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
+    if (stg.flash) {
+        const int rc = x3 ? launch_flash_x3(fp, g, stream) : launch_flash_bf16(fp, g, stream);
+        if (rc != SID_OK) return rc;
+    }
+    if (!stg.merge || fp.direct) return SID_OK;
+    MergeParams mp = {};
+    mp.opart = w.opart; mp.stats = w.stats; mp.mask = mask; mp.out = out; mp.scale = scale;
+    for (int b = 0; b < kBlocks; ++b) mp.c2[b] = fp.c2[b];
+    mp.B = B; mp.H = H; mp.Nq = Nq; mp.d = d; mp.KS = g.KS; mp.nblk = nblk; mp.out_bf16 = fp.out_bf16;
+    return launch_merge(mp, stream);
+}
+
 }  // namespace
 
 extern "C" size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, int compute) {
@@ -258,7 +274,7 @@ extern "C" size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, 
     const bool x3 = compute == SID_COMPUTE_F32X3;
     if (make_geometry(B, H, N, N, d, kBlocks, x3, &g) != SID_OK) return 0;
     Workspace w;
-    carve(g, kBlocks, 2, x3, nullptr, &w);
+    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w);
     return w.bytes;
 }
 
@@ -282,7 +298,7 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     rc = make_geometry(B, H, N, N, d, kBlocks, x3, &g);
     if (rc != SID_OK) return rc;
     Workspace w;
-    carve(g, kBlocks, 2, x3, workspace, &w);
+    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w);
     if (w.bytes > workspace_bytes)
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
 
@@ -305,16 +321,14 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};
         for (int b = 0; b < kBlocks; ++b) {
-            rowjob(2 + b, ks[b], w.k[b][0], w.k[b][1], g.NKT + 1, g.k_units);
+            rowjob(2 + b, ks[b], w.k[b][0], w.k[b][1], g.NKT, g.k_units);
             rowjob(5 + b, vs[b], w.v[b][0], w.v[b][1], g.NKT, g.v_units);
             pp.job[5 + b].kind = 1;
         }
         rc = launch_pack(pp, frags, stream);
         if (rc != SID_OK) return rc;
     }
-    if (!stg.flash) return SID_OK;
-
-    // ---- flash + in-workgroup merge
+    // ---- flash
     constexpr float LOG2E = 1.4426950408889634f;
     FlashParams fp = {};
     for (int b = 0; b < kBlocks; ++b) {
@@ -325,10 +339,7 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     }
     fp.c2[0] = fp.c2[1] = T * scale * LOG2E;
     fp.c2[2] = scale * LOG2E;
-    fp.mask = mask_signed; fp.out = out; fp.scale = scale;
-    fp.B = B; fp.H = H; fp.Nq = N; fp.Nk = N; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
-    fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = kBlocks; fp.nbuf = g.NBUF; fp.out_bf16 = dtype == SID_DTYPE_BF16; fp.flag_off = (int)g.lds;
-    return x3 ? launch_flash_x3(fp, g, stream) : launch_flash_bf16(fp, g, stream);
+    return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
 }
 
 extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, int d, int compute) {
@@ -337,7 +348,7 @@ extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, i
     const bool x3 = compute == SID_COMPUTE_F32X3;
     if (make_geometry(B, H, Nq, Nk, d, 1, x3, &g) != SID_OK) return 0;
     Workspace w;
-    carve(g, 1, 1, x3, nullptr, &w);
+    carve(g, 1, 1, x3, (long long)B * H * Nq, d, nullptr, &w);
     return w.bytes;
 }
 
@@ -359,7 +370,7 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     rc = make_geometry(B, H, Nq, Nk, d, 1, x3, &g);
     if (rc != SID_OK) return rc;
     Workspace w;
-    carve(g, 1, 1, x3, workspace, &w);
+    carve(g, 1, 1, x3, (long long)B * H * Nq, d, workspace, &w);
     if (w.bytes > workspace_bytes)
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
 
@@ -375,21 +386,115 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
             frags[i] = (long long)units;
         };
         job(0, q, w.q[0][0], w.q[0][1], 0, Nq, g.NQT, g.q_units, q_layout);
-        job(1, k, w.k[0][0], w.k[0][1], 0, Nk, g.NKT + 1, g.k_units, kv_layout);
+        job(1, k, w.k[0][0], w.k[0][1], 0, Nk, g.NKT, g.k_units, kv_layout);
         job(2, v, w.v[0][0], w.v[0][1], 1, Nk, g.NKT, g.v_units, kv_layout);
         rc = launch_pack(pp, frags, stream);
         if (rc != SID_OK) return rc;
     }
-    if (!stg.flash) return SID_OK;
-
     constexpr float LOG2E = 1.4426950408889634f;
     FlashParams fp = {};
     fp.q[0] = w.q[0][0]; fp.q_lo[0] = w.q[0][1];
     fp.k[0] = w.k[0][0]; fp.k_lo[0] = w.k[0][1];
     fp.v[0] = w.v[0][0]; fp.v_lo[0] = w.v[0][1];
     fp.c2[0] = logit_scale * LOG2E;
-    fp.mask = nullptr; fp.out = out; fp.scale = 1.f;
-    fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
-    fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = 1; fp.nbuf = g.NBUF; fp.out_bf16 = dtype == SID_DTYPE_BF16; fp.flag_off = (int)g.lds;
-    return x3 ? launch_flash_x3(fp, g, stream) : launch_flash_bf16(fp, g, stream);
+    return run_flash_merge(fp, g, w, stg, nullptr, out, 1.f, B, H, Nq, Nk, d, 1, dtype, x3, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// merge: per query row, statistics -> mask bias, then the softmax over the concatenated parts
+// ------------------------------------------------------------------------------------------
+namespace sid_attn {
+
+// One thread per (row, VEC output columns).  The statistics of a row are re-read by the d/VEC
+// threads that share it; they are 16 bytes per part and stay in L1/L2.
+template <int VEC>
+__global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
+    const int dpv = P.d / VEC;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)P.B * P.H * P.Nq * dpv;
+    if (gid >= total) return;
+    // thread order follows the OUTPUT layout (b, q, h, c): coalesced stores
+    const int c = (int)(gid % dpv);
+    long long t = gid / dpv;
+    const int h = (int)(t % P.H); t /= P.H;
+    const int q = (int)(t % P.Nq);
+    const int b = (int)(t / P.Nq);
+    const int bh = b * P.H + h;
+    const int BH = P.B * P.H;
+    const int nparts = P.nblk * P.KS;
+    constexpr float LOG2E = 1.4426950408889634f;
+    auto stat = [&](int p) { return *(const f32x4*)(P.stats + (((size_t)p * BH + bh) * P.Nq + q) * 4); };
+
+    float bias2[kBlocks] = {0.f, 0.f, 0.f};
+    if (P.nblk == kBlocks) {
+        float bmax[kBlocks], cmin = SID_INF;
+#pragma unroll
+        for (int blk = 0; blk < kBlocks; ++blk) {
+            float mx = -SID_INF;
+            for (int ks = 0; ks < P.KS; ++ks) {
+                const f32x4 st = stat(blk * P.KS + ks);
+                mx = fmaxf(mx, st[2]);
+                if (blk == kBlocks - 1) cmin = fminf(cmin, st[3]);
+            }
+            bmax[blk] = mx;
+        }
+        // min_j (q_cnt.k_cnt * scale): scaling by a constant is monotone, so it commutes with min
+        const float min_cc = (P.scale >= 0.f) ? __fmul_rn(cmin, P.scale) : __fmul_rn(bmax[2], P.scale);
+        const float m = P.mask[(size_t)b * P.Nq + q];
+        bias2[0] = __fmul_rn(__fsub_rn(min_cc, bmax[0]), __fmul_rn(m, -1.0f)) * LOG2E;
+        bias2[1] = __fmul_rn(__fsub_rn(min_cc, bmax[1]), __fmul_rn(m, 1.0f)) * LOG2E;
+    }
+    // reference of the combined softmax: the largest biased logit of the row (the true maxima, not
+    // the parts' own references, which a logit may exceed by up to 2^kOverflowThr)
+    float M2 = -SID_INF;
+    for (int p = 0; p < nparts; ++p) {
+        const f32x4 st = stat(p);
+        const float cp = P.c2[p / P.KS];
+        if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias2[p / P.KS]);
+    }
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    float den = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        const f32x4 st = stat(p);
+        if (!(st[1] > 0.f)) continue;
+        const float w = __builtin_amdgcn_exp2f(st[0] + bias2[p / P.KS] - M2);
+        den += w * st[1];
+        const float* op = P.opart + (((size_t)p * BH + bh) * P.Nq + q) * P.d + c * VEC;
+        if (VEC == 4) {
+            const f32x4 o = *(const f32x4*)op;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * o[e];
+        } else {
+            acc[0] += w * op[0];
+        }
+    }
+    const float inv = 1.0f / den;
+    const size_t oidx = ((size_t)b * P.Nq + q) * P.H * P.d + (size_t)h * P.d + c * VEC;
+    if (P.out_bf16) {
+        __bf16* o = (__bf16*)P.out + oidx;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (__bf16)(acc[e] * inv);
+    } else {
+        float* o = (float*)P.out + oidx;
+        if (VEC == 4) {
+            f32x4 r = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+            *(f32x4*)o = r;
+        } else {
+            o[0] = acc[0] * inv;
+        }
+    }
+}
+
+int launch_merge(const MergeParams& mp, hipStream_t stream) {
+    const int vec = (mp.d & 3) == 0 ? 4 : 1;
+    const long long total = (long long)mp.B * mp.H * mp.Nq * (mp.d / vec);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (vec == 4) hipLaunchKernelGGL(merge_kernel<4>, dim3(blocks), dim3(256), 0, stream, mp);
+    else hipLaunchKernelGGL(merge_kernel<1>, dim3(blocks), dim3(256), 0, stream, mp);
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}
+
+}  // namespace sid_attn

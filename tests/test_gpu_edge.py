@@ -1,0 +1,199 @@
+"""GPU parity, edge cases and size-independent properties of the attention and filter kernels.
+
+Edge cases follow the branches of the reference's forward (ldm/modules/attention.py:370-604): any
+temperature and gamma the config may carry, 77-key cross-attention, ragged token counts, batches
+with one mask per image, bf16 storage.  Full-size checks use properties that need no N x 3N oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sid_oracle as orc
+from helpers import rel_err
+from style_transfer_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16": 2e-2, "fp32": 1e-3}
+
+
+def g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def run(t, m, gamma, T, scale, H, compute, dtype=torch.float32):
+    tt = {k: g(v).to(dtype) for k, v in t.items()}
+    out = ops.injected_attention(tt["xq"], tt["q_cnt"], tt["k1"], tt["v1"], tt["k2"], tt["v2"], tt["k_cnt"],
+                                 tt["v_cnt"], g(m), gamma, T, scale, H, compute=compute)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def oracle_rows(rows, t, m, gamma, T, scale, b=0, H=8):
+    sl = slice(b * H, (b + 1) * H)
+    return orc.injected_attention_rows(rows, t["xq"][b], t["q_cnt"][sl], t["k1"][sl], t["v1"][sl], t["k2"][sl],
+                                       t["v2"][sl], t["k_cnt"][sl], t["v_cnt"][sl], m, gamma, T, scale)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("gamma,T,sgn", [(0.0, 1.5, 1), (1.0, 0.0, 1), (0.75, -1.5, 1), (0.75, 1.5, -1), (0.3, 1e-3, 1)])
+def test_injected_parameter_corners(gamma, T, sgn, compute):
+    """gamma = 0 (query from the latent only), T = 0 (uniform style blocks), negative temperature and
+    negative scale (the row reference becomes the row minimum)."""
+    H, N, d = 8, 256, 40
+    t = synth.attention_inputs(4100, H, N, d, 1.0, 1.0, 1)
+    m = np.sign(synth.normal(4101, (N,))).astype(np.float32)
+    scale = sgn * d ** -0.5
+    out = run(t, m, gamma, T, scale, H, compute)[0]
+    ref = oracle_rows(np.arange(N), t, m, gamma, T, scale)
+    assert np.isfinite(out).all()
+    assert rel_err(out, ref) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+def test_injected_logits_that_outgrow_the_first_stage(compute):
+    """A key far down the sequence whose logit exceeds everything in the first 64 keys by more than
+    2^96: the kernel's fixed softmax reference is invalid for those rows and the exact-rescale
+    fallback pass must take over.  Rows with mask = -1 see the same key pushed down by the bias."""
+    H, N, d = 8, 1024, 40
+    t = synth.attention_inputs(4200, H, N, d, 1.0, 1.0, 1)
+    u = np.zeros(d, np.float32); u[3] = 1.0
+    t["q_cnt"] = t["q_cnt"] + 3.0 * u
+    t["k1"][:, 777] = 400.0 * u          # raw q.k about 400*(3*gamma + noise)
+    t["k_cnt"][:, 901] = -300.0 * u      # very negative content logit: min_j cc far below the rest
+    m = np.sign(synth.normal(4201, (N,))).astype(np.float32)
+    gamma, T, scale = 0.75, 1.5, d ** -0.5
+    # the construction really leaves the safe range of a fixed reference
+    q = orc.blend_query(t["xq"][0], t["q_cnt"], gamma)
+    r1 = np.einsum("hid,hjd->hij", q[:, :64], t["k1"]) * (T * scale)
+    assert ((r1[:, :, 777] - r1[:, :, :64].max(-1)) * np.log2(np.e) > 96).any()
+    out = run(t, m, gamma, T, scale, H, compute)[0]
+    ref = oracle_rows(np.arange(N), t, m, gamma, T, scale)
+    assert np.isfinite(out).all()
+    assert rel_err(out, ref) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+def test_plain_logits_that_outgrow_the_first_stage(compute):
+    H, N, d = 8, 512, 64
+    q = synth.normal(4300, (H, N, d)); k = synth.normal(4301, (H, N, d)); v = synth.normal(4302, (H, N, d))
+    q[:, :, 5] += 2.0
+    k[:, 300, :] = 0; k[:, 300, 5] = 250.0
+    out = ops.plain_attention(g(q), g(k), g(v), d ** -0.5, H, "bhnd", "bhnd", compute)[0].cpu().numpy()
+    ref = orc.plain_attention(q, k, v, d ** -0.5, dtype=np.float64)
+    assert np.isfinite(out).all()
+    assert rel_err(out, ref) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("Nq,Nk,d", [(4096, 77, 40), (1024, 77, 80), (256, 77, 160), (64, 77, 160), (50, 1, 40),
+                                     (33, 31, 64), (1, 200, 96), (100, 65, 128)])
+def test_cross_attention_shapes(Nq, Nk, d, compute):
+    """Nq != Nk: the text cross-attention of the UNet (77 keys) at every resolution, plus ragged sizes."""
+    H = 8
+    q = synth.normal(4400 + Nq, (1, Nq, H * d)); k = synth.normal(4401 + Nk, (1, Nk, H * d))
+    v = synth.normal(4402 + d, (1, Nk, H * d))
+    out = ops.plain_attention(g(q), g(k), g(v), d ** -0.5, H, "bnhd", "bnhd", compute)[0].cpu().numpy()
+    ref = orc.plain_attention(orc.split_heads(q[0], H), orc.split_heads(k[0], H), orc.split_heads(v[0], H),
+                              d ** -0.5, dtype=np.float64)
+    assert rel_err(out, ref) < TOL[compute]
+
+
+@pytest.mark.parametrize("ks,nw", [(3, 1), (2, 2), (5, 4), (8, 4)])
+def test_forced_key_splits_and_workgroup_widths(ks, nw, monkeypatch):
+    """Every decomposition gives the same rows: key ranges split over several workgroups (merged by
+    statistics) and 1/2/4 waves sharing a stage."""
+    monkeypatch.setenv("SID_TUNE_KS", str(ks))
+    monkeypatch.setenv("SID_TUNE_NW", str(nw))
+    H, N, d = 8, 1000, 40            # ragged: 31.25 key tiles
+    t = synth.attention_inputs(4500, H, N, d, 1.0, 1.0, 1)
+    m = np.sign(synth.normal(4501, (N,))).astype(np.float32)
+    out = run(t, m, 0.75, 1.5, d ** -0.5, H, "fp32")[0]
+    rows = np.arange(0, N, 7)
+    assert rel_err(out[rows], oracle_rows(rows, t, m, 0.75, 1.5, d ** -0.5)) < 1e-3
+    q = synth.normal(4502, (H, N, d))
+    o2 = ops.plain_attention(g(q), g(t["k1"]), g(t["v1"]), d ** -0.5, H, "bhnd", "bhnd", "fp32")[0].cpu().numpy()
+    assert rel_err(o2, orc.plain_attention(q, t["k1"], t["v1"], d ** -0.5, dtype=np.float64)) < 1e-3
+
+
+def test_batch_with_one_mask_per_image():
+    H, N, d, B = 8, 256, 40, 3
+    t = synth.attention_inputs(4600, H, N, d, 1.0, 1.0, B)
+    m = np.sign(synth.normal(4601, (B, N))).astype(np.float32)
+    out = run(t, m, 0.75, 1.5, d ** -0.5, H, "fp32")
+    for b in range(B):
+        ref = oracle_rows(np.arange(N), t, m[b], 0.75, 1.5, d ** -0.5, b=b)
+        assert rel_err(out[b], ref) < 1e-3, b
+
+
+def test_bf16_storage():
+    """bf16 tensors in, bf16 out: the result equals the f32 path on the same (bf16-rounded) inputs
+    up to the output rounding."""
+    H, N, d = 8, 512, 40
+    t = synth.attention_inputs(4700, H, N, d, 1.0, 1.0, 1)
+    t = {k: torch.from_numpy(v).to(torch.bfloat16).float().numpy() for k, v in t.items()}
+    m = np.sign(synth.normal(4701, (N,))).astype(np.float32)
+    o16 = run(t, m, 0.75, 1.5, d ** -0.5, H, "bf16", torch.bfloat16)[0]
+    o32 = run(t, m, 0.75, 1.5, d ** -0.5, H, "bf16", torch.float32)[0]
+    assert rel_err(o16, o32) < 2 ** -8
+    rows = np.arange(0, N, 5)
+    assert rel_err(o16[rows], oracle_rows(rows, t, m, 0.75, 1.5, d ** -0.5)) < 2e-2
+
+
+# ------------------------------------------------------------------------------ full-size properties
+FULL = [(2, 4096, 40), (2, 1024, 80)]
+
+
+@pytest.mark.parametrize("B,N,d", FULL)
+def test_full_size_rows_sum_to_one(B, N, d):
+    """V = 1 everywhere: every output element is the sum of a softmax row, i.e. 1."""
+    H = 8
+    t = synth.attention_inputs(4800, H, N, d, 1.0, 1.0, B)
+    for k in ("v1", "v2", "v_cnt"):
+        t[k] = np.ones_like(t[k])
+    m = np.sign(synth.normal(4801, (B, N))).astype(np.float32)
+    out = run(t, m, 0.75, 1.5, d ** -0.5, H, "bf16")
+    assert np.abs(out - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,N,d", FULL)
+def test_full_size_style_swap_symmetry(B, N, d):
+    """Exchanging the two styles and negating the mask is the same softmax with two key blocks
+    permuted (attention.py:273, 285-288: the blocks differ only by the sign of mask*ch)."""
+    H = 8
+    t = synth.attention_inputs(4900, H, N, d, 1.0, 1.0, B)
+    m = synth.uniform(4901, (B, N)).astype(np.float32) * 2 - 1
+    a = run(t, m, 0.75, 1.5, d ** -0.5, H, "fp32")
+    t2 = dict(t, k1=t["k2"], v1=t["v2"], k2=t["k1"], v2=t["v1"])
+    b = run(t2, -m, 0.75, 1.5, d ** -0.5, H, "fp32")
+    assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,d", FULL)
+def test_full_size_sampled_rows_and_value_linearity(B, N, d):
+    H = 8
+    t = synth.attention_inputs(5000, H, N, d, 1.0, 1.0, B)
+    m = np.sign(synth.normal(5001, (B, N))).astype(np.float32)
+    out = run(t, m, 0.75, 1.5, d ** -0.5, H, "fp32")
+    rows = (synth.hash_u64(5002, 24) % np.uint64(N)).astype(np.int64)
+    for b in range(B):
+        assert rel_err(out[b][rows], oracle_rows(rows, t, m[b], 0.75, 1.5, d ** -0.5, b=b)) < 1e-3
+    # the output is linear in V: out(2 v) = 2 out(v)
+    t2 = dict(t, v1=2 * t["v1"], v2=2 * t["v2"], v_cnt=2 * t["v_cnt"])
+    assert rel_err(run(t2, m, 0.75, 1.5, d ** -0.5, H, "fp32"), 2 * out) < 1e-6
+
+
+def test_hf_filter_idempotent_linear_and_complementary():
+    """The radius filter is a projection in frequency space: applying it twice changes nothing, it is
+    linear, and a radius of zero keeps everything."""
+    for shape, ratio in [((2, 320, 64, 64), 0.5), ((1, 640, 32, 32), 0.5), ((1, 1280, 16, 16), 0.5), ((1, 1280, 8, 8), 0.3)]:
+        a, b = g(synth.normal(5100, shape)), g(synth.normal(5101, shape))
+        fa = ops.hf_filter(a, ratio)
+        assert rel_err(ops.hf_filter(fa, ratio).cpu().numpy(), fa.cpu().numpy()) < 1e-5
+        fab = ops.hf_filter(a + 2 * b, ratio)
+        assert rel_err(fab.cpu().numpy(), (fa + 2 * ops.hf_filter(b, ratio)).cpu().numpy()) < 1e-5
+        assert rel_err(ops.hf_filter(a, 0.0).cpu().numpy(), a.cpu().numpy()) < 1e-5
+        # energy: ||x||^2 = ||HF x||^2 + ||x - HF x||^2 (orthogonal projection)
+        x, f = a.double(), fa.double()
+        assert abs(((f ** 2).sum() + ((x - f) ** 2).sum()) / (x ** 2).sum() - 1) < 1e-5

@@ -30,7 +30,7 @@ def timed(flags):
         ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H, compute=compute, flags=flags)
     ev1.record(); ev1.synchronize()
     return ev0.elapsed_time(ev1) / reps
-tp, tf = timed(0x10), timed(0x20)
+tp, tf, tm = timed(0x10), timed(0x20), timed(0x40)
 fl = 12.0 * B * H * N * N * d
-print("N=%d d=%d B=%d: call %.1f us (%.1f TF/s) | pack %.1f us | flash %.1f us (%.1f TF/s = %.1f%% of 2.5 PF)" % (
-    N, d, B, t * 1e3, fl / (t * 1e-3) / 1e12, tp * 1e3, tf * 1e3, fl / (tf * 1e-3) / 1e12, fl / (tf * 1e-3) / 2.5e15 * 100))
+print("N=%d d=%d B=%d: call %.1f us (%.1f TF/s) | pack %.1f us | merge %.1f us | flash %.1f us (%.1f TF/s = %.1f%% of 2.5 PF)" % (
+    N, d, B, t * 1e3, fl / (t * 1e-3) / 1e12, tp * 1e3, tm * 1e3, tf * 1e3, fl / (tf * 1e-3) / 1e12, fl / (tf * 1e-3) / 2.5e15 * 100))
