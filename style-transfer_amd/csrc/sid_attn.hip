@@ -47,6 +47,7 @@ struct PackJob {
     long long sb, sh, sn, sb2, sh2, sn2;
     float c1, c2;       // value = src*c1 + src2*c2 when src2 != null, else src
     int kind;           // 0: row fragments (Q, K)   1: transposed V fragments with ones column
+    int vec4;           // kind 0, f32: every source row chunk is 16-byte aligned
     int N;              // valid rows
     int NT;             // 32-row tiles in the image (>= ceil(N/32)); rows >= N are zero
     int first_block;    // first blockIdx.x of this job
@@ -66,6 +67,10 @@ __device__ __forceinline__ float load_elem(const void* p, long long idx) {
     return ((const float*)p)[idx];
 }
 
+// One thread per 16-byte fragment.  Row fragments (Q, K) are 8 consecutive elements of one source
+// row, so threads are ordered (tile, row, chunk): consecutive lanes read consecutive 32-byte chunks of
+// a row (coalesced, two 16-byte loads each when the rows allow it) and scatter their fragment to its
+// place in the image.  V^T fragments gather 8 keys of one column; lanes run along the row there.
 template <bool BF16IN>
 __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
     int jb = 0;
@@ -75,32 +80,53 @@ __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
     const PackJob& J = P.job[jb];
     const long long gid = (long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x;
     if (gid >= J.frags) return;
-    const int lane = (int)(gid & 63);
-    const int hh = lane >> 5, r = lane & 31;
     float val[8];
+    long long dst;
     if (J.kind == 0) {
-        const long long t = gid >> 6;
-        const int s = (int)(t % P.DKS);
-        const long long t2 = t / P.DKS;
+        const int nchunk = 2 * P.DKS;
+        const int chunk = (int)(gid % nchunk);
+        const long long t1 = gid / nchunk;
+        const int r = (int)(t1 & 31);
+        const long long t2 = t1 >> 5;
         const int tile = (int)(t2 % J.NT);
         const long long bh = t2 / J.NT;
         const int b = (int)(bh / P.H), h = (int)(bh % P.H);
         const int row = tile * 32 + r;
-        const int d0 = 16 * s + 8 * hh;
+        const int d0 = 8 * chunk;
+        dst = ((bh * J.NT + tile) * P.DKS + (chunk >> 1)) * 64 + (chunk & 1) * 32 + r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int dd = d0 + j;
-            float v = 0.f;
-            if (row < J.N && dd < P.d) {
-                v = load_elem<BF16IN>(J.src, b * J.sb + h * J.sh + (long long)row * J.sn + dd);
+        for (int j = 0; j < 8; ++j) val[j] = 0.f;
+        if (row < J.N && d0 < P.d) {
+            const long long o1 = b * J.sb + h * J.sh + (long long)row * J.sn + d0;
+            const long long o2 = J.src2 ? b * J.sb2 + h * J.sh2 + (long long)row * J.sn2 + d0 : 0;
+            if (!BF16IN && J.vec4 && d0 + 8 <= P.d) {
+                const f32x4* p1 = (const f32x4*)((const float*)J.src + o1);
+                const f32x4 a0 = p1[0], a1 = p1[1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { val[j] = a0[j]; val[4 + j] = a1[j]; }
                 if (J.src2) {
-                    const float w = load_elem<BF16IN>(J.src2, b * J.sb2 + h * J.sh2 + (long long)row * J.sn2 + dd);
-                    v = __fadd_rn(__fmul_rn(v, J.c1), __fmul_rn(w, J.c2));
+                    const f32x4* p2 = (const f32x4*)((const float*)J.src2 + o2);
+                    const f32x4 w0 = p2[0], w1 = p2[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        val[j] = __fadd_rn(__fmul_rn(val[j], J.c1), __fmul_rn(w0[j], J.c2));
+                        val[4 + j] = __fadd_rn(__fmul_rn(val[4 + j], J.c1), __fmul_rn(w1[j], J.c2));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (d0 + j < P.d) {
+                        float v = load_elem<BF16IN>(J.src, o1 + j);
+                        if (J.src2) v = __fadd_rn(__fmul_rn(v, J.c1), __fmul_rn(load_elem<BF16IN>(J.src2, o2 + j), J.c2));
+                        val[j] = v;
+                    }
                 }
             }
-            val[j] = v;
         }
     } else {
+        const int lane = (int)(gid & 63);
+        const int hh = lane >> 5, r = lane & 31;
         const long long t = gid >> 6;
         const int dvb = (int)(t % P.DVB);
         const long long t1 = t / P.DVB;
@@ -111,26 +137,24 @@ __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
         const int b = (int)(bh / P.H), h = (int)(bh % P.H);
         const int dv = 32 * dvb + r;
         const int ones_col = 32 * P.DVB - 1;
+        dst = gid;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // loads are unconditional (clamped address) so that all eight are in flight together
             const int row = tile * 32 + pv_key(s2, hh, j);
-            float v = 0.f;
-            if (row < J.N) {
-                if (dv < P.d) v = load_elem<BF16IN>(J.src, b * J.sb + h * J.sh + (long long)row * J.sn + dv);
-                else if (dv == ones_col) v = 1.f;
-            }
-            val[j] = v;
+            const float x = load_elem<BF16IN>(J.src, b * J.sb + h * J.sh + (long long)min(row, J.N - 1) * J.sn + min(dv, P.d - 1));
+            val[j] = row < J.N ? (dv < P.d ? x : (dv == ones_col ? 1.f : 0.f)) : 0.f;
         }
     }
     bf16x8 hi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) hi[j] = (__bf16)val[j];
-    J.dst[gid] = as_u32x4(hi);
+    J.dst[dst] = as_u32x4(hi);
     if (J.dst_lo) {
         bf16x8 lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) lo[j] = (__bf16)(val[j] - (float)hi[j]);
-        J.dst_lo[gid] = as_u32x4(lo);
+        J.dst_lo[dst] = as_u32x4(lo);
     }
 }
 
@@ -208,18 +232,35 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, 
     w->bytes = off;
 }
 
+// element strides {batch, head, token} of a layout
+void layout_strides(int layout, int H, int N, int d, long long s[3]) {
+    if (layout == SID_LAYOUT_BHND) { s[0] = (long long)H * N * d; s[1] = (long long)N * d; s[2] = d; }
+    else { s[0] = (long long)N * H * d; s[1] = d; s[2] = (long long)H * d; }
+}
+
 void set_strides(PackJob& j, int layout, int H, int N, int d, bool second) {
-    long long sb, sh, sn;
-    if (layout == SID_LAYOUT_BHND) { sb = (long long)H * N * d; sh = (long long)N * d; sn = d; }
-    else { sb = (long long)N * H * d; sh = d; sn = (long long)H * d; }
-    if (second) { j.sb2 = sb; j.sh2 = sh; j.sn2 = sn; } else { j.sb = sb; j.sh = sh; j.sn = sn; }
+    long long s[3];
+    layout_strides(layout, H, N, d, s);
+    if (second) { j.sb2 = s[0]; j.sh2 = s[1]; j.sn2 = s[2]; } else { j.sb = s[0]; j.sh = s[1]; j.sn = s[2]; }
+}
+
+// Short key sequences take the single-launch kernel; SID_TUNE_NO_SMALL=1 forces the general path
+// (measurement and tests only).
+bool use_small_path(int Nk, int d) {
+    const char* e = getenv("SID_TUNE_NO_SMALL");
+    return small_attn_supported(Nk, d) && !(e && e[0] == '1');
 }
 
 int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream) {
     int blocks = 0;
     for (int i = 0; i < pp.njobs; ++i) {
-        pp.job[i].first_block = blocks;
-        pp.job[i].frags = frags[i];
+        PackJob& j = pp.job[i];
+        j.first_block = blocks;
+        j.frags = frags[i];
+        auto al4 = [](const void* p, long long a, long long b, long long c) {
+            return ((uintptr_t)p & 15) == 0 && a % 4 == 0 && b % 4 == 0 && c % 4 == 0;
+        };
+        j.vec4 = j.kind == 0 && !pp.in_bf16 && al4(j.src, j.sb, j.sh, j.sn) && (!j.src2 || al4(j.src2, j.sb2, j.sh2, j.sn2));
         blocks += (int)((frags[i] + 255) / 256);
     }
     if (pp.in_bf16) hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks), dim3(256), 0, stream, pp);
@@ -345,6 +386,7 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
 extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, int d, int compute) {
     Geometry g;
     if (check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    if (use_small_path(Nk, d)) return 256;       // the single-launch path keeps nothing in the workspace
     const bool x3 = compute == SID_COMPUTE_F32X3;
     if (make_geometry(B, H, Nq, Nk, d, 1, x3, &g) != SID_OK) return 0;
     Workspace w;
@@ -366,6 +408,14 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     SID_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
     SID_CHECK_ARG(std::isfinite(logit_scale), "logit_scale must be finite");
     const bool x3 = compute == SID_COMPUTE_F32X3;
+    constexpr float LOG2E = 1.4426950408889634f;
+    if (use_small_path(Nk, d)) {
+        if (!stg.flash) return SID_OK;
+        long long qs[3], ks[3];
+        layout_strides(q_layout, H, Nq, d, qs);
+        layout_strides(kv_layout, H, Nk, d, ks);
+        return launch_small_attn(q, k, v, out, B, H, Nq, Nk, d, logit_scale * LOG2E, qs, ks, dtype == SID_DTYPE_BF16, x3, stream);
+    }
     Geometry g;
     rc = make_geometry(B, H, Nq, Nk, d, 1, x3, &g);
     if (rc != SID_OK) return rc;
@@ -391,7 +441,6 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
         rc = launch_pack(pp, frags, stream);
         if (rc != SID_OK) return rc;
     }
-    constexpr float LOG2E = 1.4426950408889634f;
     FlashParams fp = {};
     fp.q[0] = w.q[0][0]; fp.q_lo[0] = w.q[0][1];
     fp.k[0] = w.k[0][0]; fp.k_lo[0] = w.k[0][1];
@@ -413,13 +462,13 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)P.B * P.H * P.Nq * dpv;
     if (gid >= total) return;
-    // thread order follows the OUTPUT layout (b, q, h, c): coalesced stores
+    // thread order follows the PARTIALS (head, query, column): the reads, nparts times the volume of
+    // the writes, are contiguous across the wave
     const int c = (int)(gid % dpv);
-    long long t = gid / dpv;
-    const int h = (int)(t % P.H); t /= P.H;
+    const long long t = gid / dpv;
     const int q = (int)(t % P.Nq);
-    const int b = (int)(t / P.Nq);
-    const int bh = b * P.H + h;
+    const int bh = (int)(t / P.Nq);
+    const int b = bh / P.H, h = bh % P.H;
     const int BH = P.B * P.H;
     const int nparts = P.nblk * P.KS;
     constexpr float LOG2E = 1.4426950408889634f;

@@ -92,6 +92,12 @@ int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stre
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_merge(const MergeParams& mp, hipStream_t stream);
 
+// Single-launch path for short key sequences (sid_attn_small.hip): reads the caller's tensors
+// directly (element strides {batch, head, token}), needs no workspace.
+bool small_attn_supported(int Nk, int d);
+int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream);
+
 #if defined(__HIPCC__)
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }

@@ -1,0 +1,280 @@
+// Single-launch attention for short key sequences (Nk <= 256) on gfx950.
+//
+// The 16x16 and 8x8 self-attentions of the UNet and its 77-token cross-attentions are latency
+// problems, not throughput problems: the three-kernel pipeline (pack, flash, merge) spends most of
+// its time in launches and dependent memory round trips.  Here one workgroup owns one tile of 32
+// queries of one head and does everything in one pass, reading the caller's tensors directly:
+//
+//   phase 1   wave w takes key tile w: K and Q rows -> bf16 MFMA fragments (converted in registers),
+//             S^T = K Q^T, per-query max of its 32 keys -> LDS
+//   barrier   every wave now knows the row maximum over all keys
+//             p = exp2(x - max), row sums and P (bf16, already in B-operand order) -> LDS
+//   barrier
+//   phase 2   wave b takes 32 output columns: O^T[b] = sum over key tiles of V^T[b] P^T, with the
+//             V fragments gathered from global memory (issued before phase 1, so the loads overlap
+//             it); divides by the row sum and stores.
+//
+// No workspace, no padding traffic, no partial results: HBM traffic is the tensors themselves.
+#include "sid_attn_kernel.hpp"
+
+#include <cstdint>
+
+namespace sid_attn {
+
+constexpr int kSmallMaxTiles = 8;   // key tiles (waves) per workgroup: Nk <= 256
+
+struct SmallParams {
+    const void* q; const void* k; const void* v; void* out;
+    long long qsb, qsh, qsn, ksb, ksh, ksn;     // element strides of (batch, head, token); head_dim contiguous
+    float c2;                                   // logit scale in the log2 domain
+    int H, Nq, Nk, d, NQT, nkt, ndv;            // ndv = ceil(d / 32) output column blocks
+    int out_bf16;
+};
+
+namespace {
+
+template <bool BF16IN>
+__device__ __forceinline__ float ld(const void* p, long long i) {
+    if (BF16IN) return (float)((const __bf16*)p)[i];
+    return ((const float*)p)[i];
+}
+
+// 8 consecutive elements of one row, zero beyond d or for an invalid row.  Every load is issued
+// unconditionally from a clamped address and the value discarded afterwards: predicated loads would
+// each sit in their own branch and wait for memory one after the other.
+template <bool BF16IN>
+__device__ __forceinline__ void load_row8(const void* base, long long off, int d0, int d, bool row_ok, bool vec, float (&v)[8]) {
+    if (!BF16IN && vec) {                      // d % 4 == 0: each 16-byte piece is all valid or all padding
+        const float* p = (const float*)base + off;
+        const f32x4 a = *(const f32x4*)(p + min(d0, d - 4));
+        const f32x4 b = *(const f32x4*)(p + min(d0 + 4, d - 4));
+        const bool oka = row_ok && d0 + 4 <= d, okb = row_ok && d0 + 8 <= d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = oka ? a[j] : 0.f; v[4 + j] = okb ? b[j] : 0.f; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = ld<BF16IN>(base, off + min(d0 + j, d - 1));
+            v[j] = (row_ok && d0 + j < d) ? x : 0.f;
+        }
+    }
+}
+
+template <bool X3>
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
+    if (X3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+}
+
+__device__ __forceinline__ u32x4 bits(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+
+// NKT: compile-time bound on the key tiles (2, 4 or 8), so that the V gather is one straight run of
+// loads; tiles in [nkt, NKT) read clamped addresses and are not used.
+template <int DKS, int NKT, bool X3, bool BF16IN>
+__global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(SmallParams P) {
+    __shared__ float sm_m[kSmallMaxTiles][32];
+    __shared__ float sm_l[kSmallMaxTiles][32];
+    __shared__ __attribute__((aligned(16))) u32x4 sm_p[(X3 ? 2 : 1) * kSmallMaxTiles * 2 * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5, r = lane & 31;
+    const int qt = blockIdx.x % P.NQT;
+    const int bh = blockIdx.x / P.NQT;
+    const int b = bh / P.H, h = bh % P.H;
+    const int d = P.d;
+    const long long qbase = b * P.qsb + h * P.qsh;
+    const long long kbase = b * P.ksb + h * P.ksh;
+    const bool qvec = !BF16IN && d >= 4 && ((uintptr_t)P.q & 15) == 0 && ((P.qsb | P.qsh | P.qsn) & 3) == 0;
+    const bool kvec = !BF16IN && d >= 4 && ((uintptr_t)P.k & 15) == 0 && ((P.ksb | P.ksh | P.ksn) & 3) == 0;
+
+    // ---- V^T fragments of this wave's output column block, all key tiles (loads issued first)
+    // A operand of O^T += V^T P^T: lane (r, hh) holds V[key = 32t + 16 s2 + 8 (j>>2) + 4 hh + (j&3)][32 wave + r]
+    bf16x8 vf[NKT][2], vfl[X3 ? NKT : 1][2];
+    const bool pv_wave = wave < P.ndv;
+    if (pv_wave) {
+        const int dv = 32 * wave + r;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
+                        const float x = ld<BF16IN>(P.v, kbase + (long long)min(key, P.Nk - 1) * P.ksn + min(dv, d - 1));
+                        v[j] = (key < P.Nk && dv < d) ? x : 0.f;
+                    }
+                    split8<X3>(v, vf[t][s2], vfl[X3 ? t : 0][s2]);
+                }
+            }
+        }
+    }
+
+    // ---- phase 1: logits of key tile `wave`
+    const bool qk_wave = wave < P.nkt;
+    float x[16];
+    if (qk_wave) {
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+        const int qrow = qt * 32 + r, krow = wave * 32 + r;
+#pragma unroll
+        for (int s = 0; s < DKS; ++s) {
+            float a[8], c[8];
+            load_row8<BF16IN>(P.k, kbase + (long long)min(krow, P.Nk - 1) * P.ksn, 16 * s + 8 * hh, d, krow < P.Nk, kvec, a);
+            load_row8<BF16IN>(P.q, qbase + (long long)min(qrow, P.Nq - 1) * P.qsn, 16 * s + 8 * hh, d, qrow < P.Nq, qvec, c);
+            bf16x8 kh, kl, qh, ql;
+            split8<X3>(a, kh, kl);
+            split8<X3>(c, qh, ql);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S, 0, 0, 0);
+            if (X3) {
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S, 0, 0, 0);
+            }
+        }
+        float m = -SID_INF;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            x[i] = key < P.Nk ? S[i] * P.c2 : -SID_INF;
+            m = fmaxf(m, x[i]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (hh == 0) sm_m[wave][r] = m;
+    }
+    __syncthreads();
+    if (qk_wave) {
+        float M = -SID_INF;
+        for (int t = 0; t < P.nkt; ++t) M = fmaxf(M, sm_m[t][r]);
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(x[i] - M);      // exp2(-inf) = 0 for masked keys
+        bf16x8 p0, p1, p0l, p1l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p0[j] = (__bf16)pv[j]; p1[j] = (__bf16)pv[8 + j]; }
+        float l = 0.f;
+        if (X3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p0l[j] = (__bf16)(pv[j] - (float)p0[j]);
+                p1l[j] = (__bf16)(pv[8 + j] - (float)p1[j]);
+                l += ((float)p0[j] + (float)p0l[j]) + ((float)p1[j] + (float)p1l[j]);
+            }
+        } else {
+            // the denominator sums the rounded numerators, so rounding cancels in the quotient
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l += (float)p0[j] + (float)p1[j];
+        }
+        l += __shfl_xor(l, 32);
+        if (hh == 0) sm_l[wave][r] = l;
+        sm_p[(wave * 2 + 0) * 64 + lane] = bits(p0);
+        sm_p[(wave * 2 + 1) * 64 + lane] = bits(p1);
+        if (X3) {
+            sm_p[(kSmallMaxTiles * 2 + wave * 2 + 0) * 64 + lane] = bits(p0l);
+            sm_p[(kSmallMaxTiles * 2 + wave * 2 + 1) * 64 + lane] = bits(p1l);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: output columns [32 wave, 32 wave + 32)
+    if (!pv_wave) return;
+    f32x16 O;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[i] = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        if (t < P.nkt) {
+            l += sm_l[t][r];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 p = as_bf16x8(sm_p[(t * 2 + s2) * 64 + lane]);
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s2], p, O, 0, 0, 0);
+                if (X3) {
+                    const bf16x8 pl = as_bf16x8(sm_p[(kSmallMaxTiles * 2 + t * 2 + s2) * 64 + lane]);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s2], pl, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl[X3 ? t : 0][s2], p, O, 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int q = qt * 32 + r;
+    if (q >= P.Nq) return;
+    const float inv = 1.0f / l;
+    const size_t obase = ((size_t)b * P.Nq + q) * P.H * d + (size_t)h * d;
+    const bool ovec = !P.out_bf16 && (d & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int dv0 = 32 * wave + 8 * g + 4 * hh;
+        if (ovec) {
+            if (dv0 < d) {
+                f32x4 o = {O[4 * g] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
+                *(f32x4*)((float*)P.out + obase + dv0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dv0 + e < d) {
+                    const float val = O[4 * g + e] * inv;
+                    if (P.out_bf16) ((__bf16*)P.out)[obase + dv0 + e] = (__bf16)val;
+                    else ((float*)P.out)[obase + dv0 + e] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int DKS, int NKT>
+int launch_small_inst(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
+    const dim3 grid((unsigned)(BH * p.NQT)), block(waves * 64);
+    if (x3) {
+        if (bf16in) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, true, false>), grid, block, 0, stream, p);
+    } else {
+        if (bf16in) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, false>), grid, block, 0, stream, p);
+    }
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}
+
+template <int DKS>
+int launch_small_dks(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
+    if (p.nkt <= 2) return launch_small_inst<DKS, 2>(p, BH, waves, x3, bf16in, stream);
+    if (p.nkt <= 4) return launch_small_inst<DKS, 4>(p, BH, waves, x3, bf16in, stream);
+    return launch_small_inst<DKS, 8>(p, BH, waves, x3, bf16in, stream);
+}
+
+}  // namespace
+
+bool small_attn_supported(int Nk, int d) { return Nk <= 32 * kSmallMaxTiles && (d + 31) / 32 <= kSmallMaxTiles && d <= 160; }
+
+int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream) {
+    SmallParams p = {};
+    p.q = q; p.k = k; p.v = v; p.out = out;
+    p.qsb = qs[0]; p.qsh = qs[1]; p.qsn = qs[2]; p.ksb = ks[0]; p.ksh = ks[1]; p.ksn = ks[2];
+    p.c2 = c2; p.H = H; p.Nq = Nq; p.Nk = Nk; p.d = d;
+    p.NQT = (Nq + 31) / 32; p.nkt = (Nk + 31) / 32; p.ndv = (d + 31) / 32;
+    p.out_bf16 = bf16io;
+    const int waves = p.nkt > p.ndv ? p.nkt : p.ndv;
+    const int dks = (d + 15) / 16;
+    switch (dks) {
+        case 1: case 2: return launch_small_dks<2>(p, B * H, waves, x3, bf16io, stream);
+        case 3: return launch_small_dks<3>(p, B * H, waves, x3, bf16io, stream);
+        case 4: return launch_small_dks<4>(p, B * H, waves, x3, bf16io, stream);
+        case 5: return launch_small_dks<5>(p, B * H, waves, x3, bf16io, stream);
+        case 6: return launch_small_dks<6>(p, B * H, waves, x3, bf16io, stream);
+        case 7: case 8: return launch_small_dks<8>(p, B * H, waves, x3, bf16io, stream);
+        case 9: case 10: return launch_small_dks<10>(p, B * H, waves, x3, bf16io, stream);
+    }
+    return sid::fail(SID_ENOSYS, "head_dim %d has no short-sequence kernel", d);
+}
+
+}  // namespace sid_attn

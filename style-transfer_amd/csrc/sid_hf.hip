@@ -6,6 +6,10 @@
 // independently and two real transforms cost one complex transform.  The whole H x W complex map
 // stays in LDS (128x128: 129 KB); HBM sees each input once and the output once.
 //
+// Square 16/32/64 maps (the decoder ResBlocks of the path) use the radix-8/4 kernel below
+// (hf2_kernel): each thread does whole radix-R butterflies in registers, and the map makes eight
+// round trips through LDS.  Other shapes use the general kernel:
+//
 // A length-N transform runs across the lanes of a wave (one element per lane, two for N = 128) as
 // radix-2 butterflies exchanged with wavefront shuffles.  Forward passes are decimation in
 // frequency (natural in, bit-reversed out), inverse passes decimation in time (bit-reversed in,
@@ -16,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -195,6 +201,231 @@ __global__ void __launch_bounds__(256) hf_kernel(const void* __restrict__ hcnt, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Square maps, N = R1 * R2 in {4*4, 8*4, 8*8}: two radix stages per line, butterflies in registers.
+//
+// A line x[n], n = R2*n1 + n2, goes to X[k], k = k1 + R1*k2:
+//   stage 1  for each n2: DFT_R1 over n1 (elements R2 apart), times W_N^(n2*k1), stored at R2*k1 + n2
+//   stage 2  for each k1: DFT_R2 over n2 (adjacent elements),                    stored at R2*k1 + k2
+// so position p holds bin k = p / R2 + R1 * (p % R2).  The inverse runs the same two stages backwards
+// with conjugate factors and consumes exactly that order: no reordering pass, and the middle of the
+// column transform (stage 2, mask, inverse stage 2) stays in registers.
+// ------------------------------------------------------------------------------------------
+template <bool FWD>
+__device__ __forceinline__ float2 rot90(float2 a) {           // a * (-i) forward, a * (+i) inverse
+    return FWD ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+template <int R, bool FWD>
+struct Dft;
+
+template <bool FWD>
+struct Dft<4, FWD> {
+    static __device__ __forceinline__ void run(float2 (&v)[4]) {
+        const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        const float2 t2 = cadd(v[1], v[3]), t3 = rot90<FWD>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+    }
+};
+
+template <bool FWD>
+struct Dft<8, FWD> {
+    static __device__ __forceinline__ void run(float2 (&v)[8]) {
+        float2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, FWD>::run(e);
+        Dft<4, FWD>::run(o);
+        constexpr float h = 0.70710678118654752440f;
+        const float2 a = o[1], c = o[3];
+        // W8 = (1 - i)/sqrt2 forward, (1 + i)/sqrt2 inverse; W8^3 = (-1 - i)/sqrt2, (-1 + i)/sqrt2
+        o[1] = FWD ? make_float2((a.x + a.y) * h, (a.y - a.x) * h) : make_float2((a.x - a.y) * h, (a.x + a.y) * h);
+        o[2] = rot90<FWD>(o[2]);
+        o[3] = FWD ? make_float2((c.y - c.x) * h, (-c.x - c.y) * h) : make_float2((-c.x - c.y) * h, (c.x - c.y) * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[4 + k] = csub(e[k], o[k]); }
+    }
+};
+
+template <bool BF16>
+__device__ __forceinline__ void ld4(const void* p, size_t i, float (&v)[4]) {
+    if (BF16) {
+        const uint2 raw = *(const uint2*)((const __bf16*)p + i);
+        v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+        v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    } else {
+        const float4 f = *(const float4*)((const float*)p + i);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    }
+}
+
+template <int N, int THREADS, bool BF16>
+__global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ hcnt, const void* __restrict__ skip,
+                                                      const void* __restrict__ hres, void* __restrict__ out, int C,
+                                                      int pairs_per_b, int radius2) {
+    constexpr int R1 = N == 16 ? 4 : 8, R2 = N / R1;
+    constexpr int LD = N + 1;
+    __shared__ float2 T[64];                 // exp(-2*pi*i*j/64)
+    __shared__ float2 buf[N * LD];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float s, c;
+        sincospif(-(float)tid / 32.0f, &s, &c);
+        T[tid] = make_float2(c, s);
+    }
+    const int b = blockIdx.x / pairs_per_b, pc = blockIdx.x % pairs_per_b;
+    const int c0 = 2 * pc;
+    const bool two = c0 + 1 < C;
+    const size_t base_a = ((size_t)b * C + c0) * N * N;
+    const size_t base_b = base_a + (size_t)N * N;
+
+    // ---- load: z = a + i b, rows contiguous, 4 elements per thread and step
+    for (int i = tid; i < N * N / 4; i += THREADS) {
+        const int y = (4 * i) / N, x = (4 * i) % N;
+        float a[4], bb[4] = {0.f, 0.f, 0.f, 0.f};
+        ld4<BF16>(hcnt, base_a + 4 * (size_t)i, a);
+        if (two) ld4<BF16>(hcnt, base_b + 4 * (size_t)i, bb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) buf[y * LD + x + j] = make_float2(a[j], bb[j]);
+    }
+    __syncthreads();
+
+    // twiddle W_N^e (forward) from the 64-entry table
+    auto tw = [&](int e) { return T[(e % N) * (64 / N)]; };
+
+    // One pass over all lines.  ROWS: line = row, positions along x; else line = column.
+    // Work item = (line, j): line fastest, so that a wave's lanes touch different lines.
+    auto addr = [&](bool rows, int line, int p) { return rows ? line * LD + p : p * LD + line; };
+
+    auto stage1_fwd = [&](bool rows) {
+        for (int w = tid; w < N * R2; w += THREADS) {
+            const int line = w % N, n2 = w / N;
+            float2 v[R1];
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) v[n1] = buf[addr(rows, line, R2 * n1 + n2)];
+            Dft<R1, true>::run(v);
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) buf[addr(rows, line, R2 * k1 + n2)] = k1 ? cmul(v[k1], tw(n2 * k1)) : v[k1];
+        }
+        __syncthreads();
+    };
+    auto stage2_fwd = [&](bool rows) {
+        for (int w = tid; w < N * R1; w += THREADS) {
+            const int line = w % N, k1 = w / N;
+            float2 v[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) v[n2] = buf[addr(rows, line, R2 * k1 + n2)];
+            Dft<R2, true>::run(v);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) buf[addr(rows, line, R2 * k1 + k2)] = v[k2];
+        }
+        __syncthreads();
+    };
+    auto stage2_inv = [&](bool rows) {
+        for (int w = tid; w < N * R1; w += THREADS) {
+            const int line = w % N, k1 = w / N;
+            float2 v[R2];
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) v[k2] = buf[addr(rows, line, R2 * k1 + k2)];
+            Dft<R2, false>::run(v);
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) buf[addr(rows, line, R2 * k1 + n2)] = (k1 && n2) ? cmulc(v[n2], tw(n2 * k1)) : v[n2];
+        }
+        __syncthreads();
+    };
+    auto stage1_inv = [&](bool rows) {
+        for (int w = tid; w < N * R2; w += THREADS) {
+            const int line = w % N, n2 = w / N;
+            float2 v[R1];
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) v[k1] = buf[addr(rows, line, R2 * k1 + n2)];
+            Dft<R1, false>::run(v);
+#pragma unroll
+            for (int n1 = 0; n1 < R1; ++n1) buf[addr(rows, line, R2 * n1 + n2)] = v[n1];
+        }
+        __syncthreads();
+    };
+
+    stage1_fwd(true);
+    stage2_fwd(true);
+    stage1_fwd(false);
+    // columns: stage 2, mask (with the 1/(N*N) of the two ortho norms), inverse stage 2 -- in registers
+    {
+        constexpr float norm = 1.0f / (float)(N * N);
+        for (int w = tid; w < N * R1; w += THREADS) {
+            const int col = w % N, k1 = w / N;
+            const int kx = col / R2 + R1 * (col % R2);
+            const int fx = kx < N / 2 ? kx : kx - N;
+            float2 v[R2];
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) v[n2] = buf[(R2 * k1 + n2) * LD + col];
+            Dft<R2, true>::run(v);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) {
+                const int ky = k1 + R1 * k2;
+                const int fy = ky < N / 2 ? ky : ky - N;
+                const float g = (fy * fy + fx * fx >= radius2) ? norm : 0.f;
+                v[k2] = make_float2(v[k2].x * g, v[k2].y * g);
+            }
+            Dft<R2, false>::run(v);
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) buf[(R2 * k1 + n2) * LD + col] = (k1 && n2) ? cmulc(v[n2], tw(n2 * k1)) : v[n2];
+        }
+        __syncthreads();
+    }
+    stage1_inv(false);
+    stage2_inv(true);
+    stage1_inv(true);
+
+    // ---- store: real part -> map a, imaginary part -> map b; fused residual sum
+    for (int i = tid; i < N * N / 4; i += THREADS) {
+        const int y = (4 * i) / N, x = (4 * i) % N;
+        const size_t o = 4 * (size_t)i;
+        float ra[4], rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float2 z = buf[y * LD + x + j]; ra[j] = z.x; rb[j] = z.y; }
+        if (skip) {
+            float s[4], h[4];
+            ld4<BF16>(skip, base_a + o, s); ld4<BF16>(hres, base_a + o, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // bf16 tensors: (skip + h) rounds to bf16, then + HF rounds again
+                if (BF16) ra[j] = (float)(__bf16)(s[j] + h[j]) + (float)(__bf16)ra[j];
+                else ra[j] = __fadd_rn(__fadd_rn(s[j], h[j]), ra[j]);
+            }
+            if (two) {
+                ld4<BF16>(skip, base_b + o, s); ld4<BF16>(hres, base_b + o, h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (BF16) rb[j] = (float)(__bf16)(s[j] + h[j]) + (float)(__bf16)rb[j];
+                    else rb[j] = __fadd_rn(__fadd_rn(s[j], h[j]), rb[j]);
+                }
+            }
+        }
+        if (BF16) {
+            __bf16* op = (__bf16*)out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                op[base_a + o + j] = (__bf16)ra[j];
+                if (two) op[base_b + o + j] = (__bf16)rb[j];
+            }
+        } else {
+            float* op = (float*)out;
+            *(float4*)(op + base_a + o) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+            if (two) *(float4*)(op + base_b + o) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        }
+    }
+}
+
+template <int N, bool BF16>
+int launch_hf2(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int radius,
+               hipStream_t stream) {
+    constexpr int THREADS = N == 64 ? 256 : (N == 32 ? 128 : 64);
+    const int pairs = (C + 1) / 2;
+    hipLaunchKernelGGL((hf2_kernel<N, THREADS, BF16>), dim3(B * pairs), dim3(THREADS), 0, stream, hcnt, skip, hres, out,
+                       C, pairs, radius * radius);
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}
+
 template <int H, int W, bool BF16>
 int launch_hf(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int radius,
               hipStream_t stream) {
@@ -217,6 +448,15 @@ int launch_hf(const void* hcnt, const void* skip, const void* hres, void* out, i
 template <bool BF16>
 int dispatch_hf(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int H, int W,
                 int radius, hipStream_t stream) {
+    // 16-byte (f32) / 8-byte (bf16) vector access needs aligned maps; H*W is a multiple of 4 here
+    const size_t al = BF16 ? 7 : 15;
+    const bool aligned = (((uintptr_t)hcnt | (uintptr_t)out | (uintptr_t)skip | (uintptr_t)hres) & al) == 0;
+    const char* e = getenv("SID_TUNE_HF_GENERAL");       // measurement and tests only
+    if (H == W && aligned && !(e && e[0] == '1')) {
+        if (H == 64) return launch_hf2<64, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
+        if (H == 32) return launch_hf2<32, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
+        if (H == 16) return launch_hf2<16, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
+    }
 #define SID_HF(h, w) if (H == h && W == w) return launch_hf<h, w, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
 #define SID_HF_ROW(h) SID_HF(h, 8) SID_HF(h, 16) SID_HF(h, 32) SID_HF(h, 64) SID_HF(h, 128)
     SID_HF_ROW(8) SID_HF_ROW(16) SID_HF_ROW(32) SID_HF_ROW(64) SID_HF_ROW(128)

@@ -89,8 +89,12 @@ def test_plain_logits_that_outgrow_the_first_stage(compute):
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
 @pytest.mark.parametrize("Nq,Nk,d", [(4096, 77, 40), (1024, 77, 80), (256, 77, 160), (64, 77, 160), (50, 1, 40),
                                      (33, 31, 64), (1, 200, 96), (100, 65, 128)])
-def test_cross_attention_shapes(Nq, Nk, d, compute):
-    """Nq != Nk: the text cross-attention of the UNet (77 keys) at every resolution, plus ragged sizes."""
+@pytest.mark.parametrize("path", ["single_launch", "general"])
+def test_cross_attention_shapes(Nq, Nk, d, compute, path, monkeypatch):
+    """Nq != Nk: the text cross-attention of the UNet (77 keys) at every resolution, plus ragged sizes,
+    through the single-launch short-sequence kernel and through the general pack/flash/merge path."""
+    if path == "general":
+        monkeypatch.setenv("SID_TUNE_NO_SMALL", "1")
     H = 8
     q = synth.normal(4400 + Nq, (1, Nq, H * d)); k = synth.normal(4401 + Nk, (1, Nk, H * d))
     v = synth.normal(4402 + d, (1, Nk, H * d))
@@ -115,6 +119,29 @@ def test_forced_key_splits_and_workgroup_widths(ks, nw, monkeypatch):
     q = synth.normal(4502, (H, N, d))
     o2 = ops.plain_attention(g(q), g(t["k1"]), g(t["v1"]), d ** -0.5, H, "bhnd", "bhnd", "fp32")[0].cpu().numpy()
     assert rel_err(o2, orc.plain_attention(q, t["k1"], t["v1"], d ** -0.5, dtype=np.float64)) < 1e-3
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Nq,Nk,d,layout", [(2, 256, 256, 160, "bnhd"), (3, 64, 64, 160, "bhnd"), (1, 70, 200, 20, "bnhd"),
+                                              (2, 40, 256, 100, "bhnd"), (1, 256, 129, 8, "bnhd")])
+def test_short_sequence_kernel(B, Nq, Nk, d, layout, dtype, compute):
+    """The single-launch kernel at the UNet's 16x16 / 8x8 self-attention shapes, with batches, both
+    layouts, both storage types and head dims the general path has no instance for."""
+    H = 8
+    mk = lambda seed, n: torch.from_numpy(synth.normal(seed, (B, n, H * d))).to(dtype)
+    q, k, v = mk(4450, Nq), mk(4451, Nk), mk(4452, Nk)
+    sp = lambda t: np.stack([orc.split_heads(x, H) for x in t.float().numpy()])          # (B, H, N, d)
+    if layout == "bhnd":
+        dev_t = lambda t: g(sp(t).reshape(B * H, -1, d)).to(dtype)
+    else:
+        dev_t = lambda t: t.to("cuda:0")
+    out = ops.plain_attention(dev_t(q), dev_t(k), dev_t(v), d ** -0.5, H, layout, layout, compute).float().cpu().numpy()
+    qs, ks_, vs = sp(q), sp(k), sp(v)
+    tol = TOL[compute] if dtype == torch.float32 else max(TOL[compute], 2 ** -7)
+    for b in range(B):
+        ref = orc.plain_attention(qs[b], ks_[b], vs[b], d ** -0.5, dtype=np.float64)
+        assert rel_err(out[b], ref) < tol, b
 
 
 def test_batch_with_one_mask_per_image():
@@ -197,3 +224,21 @@ def test_hf_filter_idempotent_linear_and_complementary():
         # energy: ||x||^2 = ||HF x||^2 + ||x - HF x||^2 (orthogonal projection)
         x, f = a.double(), fa.double()
         assert abs(((f ** 2).sum() + ((x - f) ** 2).sum()) / (x ** 2).sum() - 1) < 1e-5
+
+
+@pytest.mark.parametrize("path", ["radix", "general"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hf_filter_both_kernels(path, dtype, monkeypatch):
+    """Square 16/32/64 maps through the register-butterfly kernel and through the general
+    lane-shuffle kernel, f32 and bf16 storage, odd channel counts, fused and bare."""
+    if path == "general":
+        monkeypatch.setenv("SID_TUNE_HF_GENERAL", "1")
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    for n, c, ratio in [(64, 3, 0.5), (32, 5, 0.5), (16, 4, 0.5), (64, 2, 0.2), (32, 1, 0.9), (16, 7, 0.3)]:
+        rd = lambda seed: torch.from_numpy(synth.normal(seed, (2, c, n, n))).to(dtype)
+        x, s, h = rd(5200 + n), rd(5201 + n), rd(5202 + n)
+        got = ops.hf_filter(x.cuda(), ratio, skip=s.cuda(), h=h.cuda()).float().cpu().numpy()
+        want = orc.resblock_hf_merge(s.float().numpy(), h.float().numpy(), x.float().numpy(), ratio)
+        assert rel_err(got, want) < tol, (n, c, ratio)
+        bare = ops.hf_filter(x.cuda(), ratio).float().cpu().numpy()
+        assert rel_err(bare, orc.high_freq_filter(x.float().numpy(), ratio)) < tol, (n, c, ratio)
