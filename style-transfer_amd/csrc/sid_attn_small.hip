@@ -39,42 +39,57 @@ __device__ __forceinline__ float ld(const void* p, long long i) {
     return ((const float*)p)[i];
 }
 
-// 8 consecutive elements of one row, zero beyond d or for an invalid row.  Every load is issued
-// unconditionally from a clamped address and the value discarded afterwards: predicated loads would
-// each sit in their own branch and wait for memory one after the other.
-template <bool BF16IN>
-__device__ __forceinline__ void load_row8(const void* base, long long off, int d0, int d, bool row_ok, bool vec, float (&v)[8]) {
-    if (!BF16IN && vec) {                      // d % 4 == 0: each 16-byte piece is all valid or all padding
-        const float* p = (const float*)base + off;
-        const f32x4 a = *(const f32x4*)(p + min(d0, d - 4));
-        const f32x4 b = *(const f32x4*)(p + min(d0 + 4, d - 4));
-        const bool oka = row_ok && d0 + 4 <= d, okb = row_ok && d0 + 8 <= d;
+__device__ __forceinline__ u32x4 bits(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+
+// Row loads come in three flavours, chosen on the host so that the kernel has no divergent paths:
+//   MODE 0  element loads (any head_dim, any alignment)
+//   MODE 1  f32, head_dim % 4 == 0, 16-byte aligned rows: two 16-byte loads per fragment
+//   MODE 2  bf16, head_dim % 8 == 0, 16-byte aligned rows: the fragment IS one 16-byte load
+// Every load is unconditional (clamped address, value discarded afterwards) and all loads of a
+// phase are issued before the first one is consumed: a predicated or consumed-at-once load would
+// cost one memory round trip each.
+template <int MODE>
+struct RowFrag {                 // raw registers of one 8-element fragment
+    static constexpr int NV = MODE == 0 ? 8 : (MODE == 1 ? 8 : 4);
+    float raw[MODE == 2 ? 1 : 8];
+    u32x4 packed;
+    template <bool BF16IN>
+    __device__ __forceinline__ void load(const void* base, long long off, int d0, int d) {
+        if (MODE == 1) {
+            const float* p = (const float*)base + off;
+            const f32x4 a = *(const f32x4*)(p + min(d0, d - 4));
+            const f32x4 b = *(const f32x4*)(p + min(d0 + 4, d - 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = oka ? a[j] : 0.f; v[4 + j] = okb ? b[j] : 0.f; }
-    } else {
+            for (int j = 0; j < 4; ++j) { raw[j] = a[j]; raw[4 + j] = b[j]; }
+        } else if (MODE == 2) {
+            packed = *(const u32x4*)((const __bf16*)base + off + min(d0, d - 8));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = ld<BF16IN>(base, off + min(d0 + j, d - 1));
-            v[j] = (row_ok && d0 + j < d) ? x : 0.f;
+            for (int j = 0; j < 8; ++j) raw[j] = ld<BF16IN>(base, off + min(d0 + j, d - 1));
         }
     }
-}
-
-template <bool X3>
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    template <bool X3>
+    __device__ __forceinline__ void finish(bool row_ok, int d0, int d, bf16x8& hi, bf16x8& lo) const {
+        if (MODE == 2) {
+            const bool ok = row_ok && d0 + 8 <= d;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            hi = as_bf16x8(ok ? packed : z);
+            if (X3) lo = as_bf16x8(z);
+            return;
+        }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) hi[j] = (__bf16)v[j];
-    if (X3) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = row_ok && (MODE == 1 ? d0 + 4 * (j >> 2) + 4 <= d : d0 + j < d);
+            const float x = ok ? raw[j] : 0.f;
+            hi[j] = (__bf16)x;
+            if (X3) lo[j] = (__bf16)(x - (float)hi[j]);
+        }
     }
-}
-
-__device__ __forceinline__ u32x4 bits(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+};
 
 // NKT: compile-time bound on the key tiles (2, 4 or 8), so that the V gather is one straight run of
 // loads; tiles in [nkt, NKT) read clamped addresses and are not used.
-template <int DKS, int NKT, bool X3, bool BF16IN>
+template <int DKS, int NKT, bool X3, bool BF16IN, int MODE>
 __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(SmallParams P) {
     __shared__ float sm_m[kSmallMaxTiles][32];
     __shared__ float sm_l[kSmallMaxTiles][32];
@@ -89,62 +104,66 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
     const int d = P.d;
     const long long qbase = b * P.qsb + h * P.qsh;
     const long long kbase = b * P.ksb + h * P.ksh;
-    const bool qvec = !BF16IN && d >= 4 && ((uintptr_t)P.q & 15) == 0 && ((P.qsb | P.qsh | P.qsn) & 3) == 0;
-    const bool kvec = !BF16IN && d >= 4 && ((uintptr_t)P.k & 15) == 0 && ((P.ksb | P.ksh | P.ksn) & 3) == 0;
+    const bool qk_wave = wave < P.nkt;      // phase 1: this wave owns key tile `wave`
+    const bool pv_wave = wave < P.ndv;      // phase 2: this wave owns output columns [32 wave, 32 wave + 32)
 
-    // ---- V^T fragments of this wave's output column block, all key tiles (loads issued first)
-    // A operand of O^T += V^T P^T: lane (r, hh) holds V[key = 32t + 16 s2 + 8 (j>>2) + 4 hh + (j&3)][32 wave + r]
-    bf16x8 vf[NKT][2], vfl[X3 ? NKT : 1][2];
-    const bool pv_wave = wave < P.ndv;
-    if (pv_wave) {
-        const int dv = 32 * wave + r;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            {
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
-                        const float x = ld<BF16IN>(P.v, kbase + (long long)min(key, P.Nk - 1) * P.ksn + min(dv, d - 1));
-                        v[j] = (key < P.Nk && dv < d) ? x : 0.f;
-                    }
-                    split8<X3>(v, vf[t][s2], vfl[X3 ? t : 0][s2]);
-                }
-            }
-        }
-    }
-
-    // ---- phase 1: logits of key tile `wave`
-    const bool qk_wave = wave < P.nkt;
+    // ---- phase 1: logits of key tile `wave`.  All K and Q loads first, then conversions and MFMAs.
     float x[16];
     if (qk_wave) {
+        const int qrow = qt * 32 + r, krow = wave * 32 + r;
+        const long long koff = kbase + (long long)min(krow, P.Nk - 1) * P.ksn;
+        const long long qoff = qbase + (long long)min(qrow, P.Nq - 1) * P.qsn;
+        RowFrag<MODE> kr[DKS], qr[DKS];
+#pragma unroll
+        for (int s = 0; s < DKS; ++s) {
+            kr[s].template load<BF16IN>(P.k, koff, 16 * s + 8 * hh, d);
+            qr[s].template load<BF16IN>(P.q, qoff, 16 * s + 8 * hh, d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 S;
 #pragma unroll
         for (int i = 0; i < 16; ++i) S[i] = 0.f;
-        const int qrow = qt * 32 + r, krow = wave * 32 + r;
 #pragma unroll
         for (int s = 0; s < DKS; ++s) {
-            float a[8], c[8];
-            load_row8<BF16IN>(P.k, kbase + (long long)min(krow, P.Nk - 1) * P.ksn, 16 * s + 8 * hh, d, krow < P.Nk, kvec, a);
-            load_row8<BF16IN>(P.q, qbase + (long long)min(qrow, P.Nq - 1) * P.qsn, 16 * s + 8 * hh, d, qrow < P.Nq, qvec, c);
             bf16x8 kh, kl, qh, ql;
-            split8<X3>(a, kh, kl);
-            split8<X3>(c, qh, ql);
+            kr[s].template finish<X3>(krow < P.Nk, 16 * s + 8 * hh, d, kh, kl);
+            qr[s].template finish<X3>(qrow < P.Nq, 16 * s + 8 * hh, d, qh, ql);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S, 0, 0, 0);
             if (X3) {
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S, 0, 0, 0);
             }
         }
-        float m = -SID_INF;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int key = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             x[i] = key < P.Nk ? S[i] * P.c2 : -SID_INF;
-            m = fmaxf(m, x[i]);
         }
+    }
+
+    // ---- V^T fragments of this wave's output column block, all key tiles: issue every load now, so
+    // that they are in flight during the softmax exchange below.
+    // A operand of O^T += V^T P^T: lane (r, hh) holds V[key = 32t + 16 s2 + 8 (j>>2) + 4 hh + (j&3)][32 wave + r]
+    float vraw[NKT][2][8];
+    const int dv = 32 * wave + r;
+    if (pv_wave) {
+        const long long voff = kbase + min(dv, d - 1);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
+                    vraw[t][s2][j] = ld<BF16IN>(P.v, voff + (long long)min(key, P.Nk - 1) * P.ksn);
+                }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (qk_wave) {
+        float m = -SID_INF;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, x[i]);
         m = fmaxf(m, __shfl_xor(m, 32));
         if (hh == 0) sm_m[wave][r] = m;
     }
@@ -194,12 +213,20 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
             l += sm_l[t][r];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);
+                    const float val = (key < P.Nk && dv < d) ? vraw[t][s2][j] : 0.f;
+                    vh[j] = (__bf16)val;
+                    if (X3) vl[j] = (__bf16)(val - (float)vh[j]);
+                }
                 const bf16x8 p = as_bf16x8(sm_p[(t * 2 + s2) * 64 + lane]);
-                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s2], p, O, 0, 0, 0);
+                O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, p, O, 0, 0, 0);
                 if (X3) {
                     const bf16x8 pl = as_bf16x8(sm_p[(kSmallMaxTiles * 2 + t * 2 + s2) * 64 + lane]);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][s2], pl, O, 0, 0, 0);
-                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl[X3 ? t : 0][s2], p, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, O, 0, 0, 0);
+                    O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, p, O, 0, 0, 0);
                 }
             }
         }
@@ -230,18 +257,29 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
     }
 }
 
-template <int DKS, int NKT>
-int launch_small_inst(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
+template <int DKS, int NKT, bool X3>
+int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStream_t stream) {
     const dim3 grid((unsigned)(BH * p.NQT)), block(waves * 64);
-    if (x3) {
-        if (bf16in) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, true, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, true, false>), grid, block, 0, stream, p);
+    auto al = [](const void* ptr, long long a, long long b, long long c, int m) {
+        return ((uintptr_t)ptr & 15) == 0 && a % m == 0 && b % m == 0 && c % m == 0;
+    };
+    const int m = bf16in ? 8 : 4;
+    const bool vec = p.d % m == 0 && al(p.q, p.qsb, p.qsh, p.qsn, m) && al(p.k, p.ksb, p.ksh, p.ksn, m);
+    if (bf16in) {
+        if (vec) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 0>), grid, block, 0, stream, p);
     } else {
-        if (bf16in) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, false>), grid, block, 0, stream, p);
+        if (vec) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, false, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, false, 0>), grid, block, 0, stream, p);
     }
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
+}
+
+template <int DKS, int NKT>
+int launch_small_inst(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
+    return x3 ? launch_small_x<DKS, NKT, true>(p, BH, waves, bf16in, stream)
+              : launch_small_x<DKS, NKT, false>(p, BH, waves, bf16in, stream);
 }
 
 template <int DKS>
