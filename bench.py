@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 from style_transfer_amd import lib as sid_lib  # noqa: E402
 from style_transfer_amd import ops  # noqa: E402
+from style_transfer_amd import sharding  # noqa: E402
 
 HEADS = 8
 GAMMA, TEMP, RATIO = 0.5, 1.5, 0.5
@@ -101,6 +102,17 @@ def flash_kernel_time(w, compute, reps=50):
     ev1.record()
     ev1.synchronize()
     return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
+    WRITE_SIZE, each in its own rocprofv3 run, corrected for gfx950), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flash_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("traffic_bytes")
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -188,9 +200,9 @@ def main():
         out = run_image(w, args.compute)
         latents.append(out.reshape(-1)[:4 * 64 * 64].clone())   # stand-in for the (1,4,64,64) latent, 64 KiB
     mine = torch.stack(latents).float()
-    if dist is not None:                                   # the one collective of the job
-        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, gathered, dst=0)
+    gathered = sharding.gather_latents(mine, dist, dst=0)  # the one collective of the job (RCCL gather)
+    if rank == 0:
+        assert gathered.shape[0] == world and gathered.shape[1] == args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -220,9 +232,9 @@ def main():
                                    "on 6 ResBlocks for 20 evaluations; hot path only (UNet convs/VAE not run)",
                        "feature_storage": args.io, "images_per_rank": args.steps,
                        "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "flash_kernel<3,2> injected attention N=4096 d=40 H=8 B=1",
+            "roofline": {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,4> injected attention N=4096 d=40 H=8 B=1",
                          "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK, "traffic": None, "kernel_ms": t_flash * 1e3,
+                         "frac": achieved / MFMA_PEAK, "traffic": measured_traffic(), "kernel_ms": t_flash * 1e3,
                          "algorithmic_flop": flops},
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
         }

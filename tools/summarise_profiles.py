@@ -1,0 +1,49 @@
+"""Turn gpurun_out/<tag> (tools/collect_profiles.sh) into the committed summaries under profiles/."""
+import collections, csv, glob, io, json, os, re, subprocess, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+def kstats(path, skip=None):
+    return subprocess.run([sys.executable, os.path.join(root, "tools", "kstats.py"), path] + ([skip] if skip else []),
+                          capture_output=True, text=True).stdout
+
+with open(os.path.join(dst, tag + "_bench_kernel_stats.txt"), "w") as f:
+    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
+    f.write("(4 images: 1 warm-up + 3 timed; the torch normal_ kernels that create the synthetic workload are left out)\n\n")
+    f.write(kstats(os.path.join(src, "bench", "bench_kernel_stats.csv"), "at::native"))
+    f.write("\nbench line printed under the profiler:\n" + open(os.path.join(src, "bench_under_rocprof.json")).read())
+with open(os.path.join(dst, tag + "_attn4096_kernel_stats.txt"), "w") as f:
+    f.write("rocprofv3 --kernel-trace --stats -- python3 tools/prof_attn.py 4096 40 1 20   (injected attention, N=4096 d=40 H=8 B=1)\n\n")
+    f.write(kstats(os.path.join(src, "attn", "attn_kernel_stats.csv"), "at::native"))
+    f.write("\n" + open(os.path.join(src, "attn.txt")).read())
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for fn in glob.glob(src + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(fn)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines, flash = [], None
+for name, cs in acc.items():
+    if "at::" in name:
+        continue
+    short = re.sub(r"\(anonymous namespace\)::", "", name)[:90]
+    lines.append(short)
+    for c, v in sorted(cs.items()):
+        lines.append("   %-30s n=%-3d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+    if "flash_kernel" in name:
+        flash = {c: sum(v) / len(v) for c, v in cs.items()}
+with open(os.path.join(dst, tag + "_attn4096_pmc.txt"), "w") as f:
+    f.write("rocprofv3 --pmc <one pass per run> -- python3 tools/prof_attn.py 4096 40 1 3; mean per dispatch\n")
+    f.write("FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (uncorrected)\n\n" + "\n".join(lines) + "\n")
+if flash and "FETCH_SIZE" in flash:
+    # gfx950: FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 bytes -> double it;
+    # WRITE_SIZE is exact for 16-byte-per-lane stores.  Both are reported in KiB.
+    js = {"kernel": "flash_kernel, injected attention N=4096 d=40 H=8 B=1",
+          "fetch_bytes": flash["FETCH_SIZE"] * 1024 * 2, "write_bytes": flash.get("WRITE_SIZE", 0.0) * 1024,
+          "correction": "FETCH_SIZE x2 (gfx950 counts 128 B read requests as 64 B), WRITE_SIZE x1; KiB -> bytes"}
+    js["traffic_bytes"] = js["fetch_bytes"] + js["write_bytes"]
+    json.dump(js, open(os.path.join(dst, tag + "_flash_traffic.json"), "w"), indent=1)
+    print(js)
+print("\n".join(lines[:60]))
