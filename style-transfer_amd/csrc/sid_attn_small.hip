@@ -17,7 +17,9 @@
 // No workspace, no padding traffic, no partial results: HBM traffic is the tensors themselves.
 #include "sid_attn_kernel.hpp"
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 namespace sid_attn {
 
@@ -257,6 +259,256 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged variant (bf16 products, 16-byte aligned rows): every global load is a fully coalesced
+// 16-byte-per-lane read of contiguous row pieces; the MFMA operand order is produced by where the
+// converted pieces are WRITTEN in LDS.
+//   K tile w / Q tile : fragment order, unit (k-step s, half hh) at (2s + hh) * kUnit + row * 16
+//                       (kUnit = 528: the 16 spare bytes rotate the units over the banks)
+//   V                 : bf16 row-major [key][vst], written after the logits are done into the space
+//                       K and Q occupied; phase 2 gathers its A fragments with 2-byte reads
+// MODE 1: f32 input (4 elements per piece), MODE 2: bf16 input (8 elements per piece).
+// ------------------------------------------------------------------------------------------
+constexpr int kUnit = 528;
+
+template <int DKS, int MODE>
+__global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(SmallParams P, int vst, int p_off, int st_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPP = MODE == 1 ? 4 : 8;           // elements per 16-byte piece
+    constexpr int PRF = 16 * DKS / EPP;              // pieces per padded row
+    constexpr int NPT = 32 * PRF;                    // pieces per 32-row tile
+    constexpr int ITERS = NPT / 64;                  // per lane, when one wave copies one tile
+    constexpr int TILE_BYTES = 2 * DKS * kUnit;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x;
+    const int hh = lane >> 5, r = lane & 31;
+    const int qt = blockIdx.x % P.NQT;
+    const int bh = blockIdx.x / P.NQT;
+    const int b = bh / P.H, h = bh % P.H;
+    const int d = P.d;
+    const int pr = d / EPP;                          // valid pieces per row
+    const long long qbase = b * P.qsb + h * P.qsh;
+    const long long kbase = b * P.ksb + h * P.ksh;
+    const bool qk_wave = wave < P.nkt, pv_wave = wave < P.ndv;
+    unsigned char* kq = smem;                        // K tiles [nkt], then the Q tile
+    unsigned char* qb = smem + P.nkt * TILE_BYTES;
+    float* sm_m = (float*)(smem + st_off);
+    float* sm_l = sm_m + kSmallMaxTiles * 32;
+    u32x4* sm_p = (u32x4*)(smem + p_off);
+
+    // one 16-byte piece of a row -> registers (4 or 8 bf16), zero for padding columns
+    auto load_piece = [&](const void* base, long long rowoff, int col, u32x4& raw) {
+        const int c = min(col, pr - 1);
+        if (MODE == 1) raw = __builtin_bit_cast(u32x4, *(const f32x4*)((const float*)base + rowoff + 4 * c));
+        else raw = *(const u32x4*)((const __bf16*)base + rowoff + 8 * c);
+    };
+    auto to_bf16 = [&](const u32x4& raw, bool ok, unsigned (&o)[4]) {       // MODE 1 fills o[0..1], MODE 2 o[0..3]
+        if (MODE == 1) {
+            const f32x4 f = __builtin_bit_cast(f32x4, raw);
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 lo2 = {(__bf16)f[0], (__bf16)f[1]}, hi2 = {(__bf16)f[2], (__bf16)f[3]};
+            o[0] = ok ? __builtin_bit_cast(unsigned, lo2) : 0u;
+            o[1] = ok ? __builtin_bit_cast(unsigned, hi2) : 0u;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ok ? raw[i] : 0u;
+        }
+    };
+    // fragment-order address of piece (row, col) inside a tile image
+    auto frag_addr = [&](int row, int col) {
+        const int dd = col * EPP;
+        return ((dd >> 4) * 2 + ((dd >> 3) & 1)) * kUnit + row * 16 + (dd & 7) * 2;
+    };
+
+    // ---- issue every global load: this wave's K tile and V tile, and a share of the Q tile
+    u32x4 kraw[ITERS], vraw[ITERS];
+    if (qk_wave) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int f = i * 64 + lane, row = f / PRF, col = f % PRF;
+            const long long off = kbase + (long long)min(wave * 32 + row, P.Nk - 1) * P.ksn;
+            load_piece(P.k, off, col, kraw[i]);
+            load_piece(P.v, off, col, vraw[i]);
+        }
+    }
+    // the Q tile is shared: all threads copy it, four pieces per thread and round (one round for a
+    // workgroup of 320+ threads at head_dim 160)
+    auto store_piece = [&](unsigned char* dst, const unsigned (&o)[4]) {
+        if (MODE == 1) { u32x2 w2 = {o[0], o[1]}; *(u32x2*)dst = w2; }
+        else { u32x4 w4 = {o[0], o[1], o[2], o[3]}; *(u32x4*)dst = w4; }
+    };
+    for (int f0 = 0; f0 < NPT; f0 += 4 * nthreads) {
+        u32x4 qraw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = min(f0 + i * nthreads + tid, NPT - 1), row = f / PRF, col = f % PRF;
+            load_piece(P.q, qbase + (long long)min(qt * 32 + row, P.Nq - 1) * P.qsn, col, qraw[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + i * nthreads + tid;
+            if (f < NPT) {
+                const int row = f / PRF, col = f % PRF;
+                unsigned o[4];
+                to_bf16(qraw[i], col < pr, o);
+                store_piece(qb + frag_addr(row, col), o);
+            }
+        }
+    }
+
+    // ---- K into LDS in fragment order
+    if (qk_wave) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int f = i * 64 + lane, row = f / PRF, col = f % PRF;
+            unsigned o[4];
+            to_bf16(kraw[i], col < pr, o);
+            store_piece(kq + wave * TILE_BYTES + frag_addr(row, col), o);
+        }
+    }
+    // V converted now (frees the raw registers), written after the logits
+    unsigned vb16[ITERS][MODE == 1 ? 2 : 4];
+    if (qk_wave) {
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            unsigned o[4];
+            to_bf16(vraw[i], true, o);
+#pragma unroll
+            for (int e = 0; e < (MODE == 1 ? 2 : 4); ++e) vb16[i][e] = o[e];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: logits of key tile `wave`
+    float x[16];
+    if (qk_wave) {
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DKS; ++s) {
+            const bf16x8 kf = as_bf16x8(*(const u32x4*)(kq + wave * TILE_BYTES + (2 * s + hh) * kUnit + r * 16));
+            const bf16x8 qf = as_bf16x8(*(const u32x4*)(qb + (2 * s + hh) * kUnit + r * 16));
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, S, 0, 0, 0);
+        }
+        float m = -SID_INF;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            x[i] = key < P.Nk ? S[i] * P.c2 : -SID_INF;
+            m = fmaxf(m, x[i]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (hh == 0) sm_m[wave * 32 + r] = m;
+    }
+    __syncthreads();          // maxima visible; nobody reads the K/Q images any more
+
+    if (qk_wave) {
+        // V tile -> LDS row-major bf16, over the K/Q images
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int f = i * 64 + lane, row = f / PRF, col = f % PRF;
+            if (col < pr) {
+                unsigned char* dst = smem + (wave * 32 + row) * vst + col * EPP * 2;
+                if (MODE == 1) { u32x2 w2 = {vb16[i][0], vb16[i][1]}; *(u32x2*)dst = w2; }
+                else { u32x4 w4 = {vb16[i][0], vb16[i][1], vb16[i][MODE == 1 ? 0 : 2], vb16[i][MODE == 1 ? 1 : 3]}; *(u32x4*)dst = w4; }
+            }
+        }
+        float M = -SID_INF;
+        for (int t = 0; t < P.nkt; ++t) M = fmaxf(M, sm_m[t * 32 + r]);
+        float pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(x[i] - M);      // exp2(-inf) = 0 for masked keys
+        bf16x8 p0, p1;
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p0[j] = (__bf16)pv[j]; p1[j] = (__bf16)pv[8 + j];
+            l += (float)p0[j] + (float)p1[j];      // the denominator sums the rounded numerators
+        }
+        l += __shfl_xor(l, 32);
+        if (hh == 0) sm_l[wave * 32 + r] = l;
+        sm_p[(wave * 2 + 0) * 64 + lane] = bits(p0);
+        sm_p[(wave * 2 + 1) * 64 + lane] = bits(p1);
+    }
+    __syncthreads();
+
+    // ---- phase 2: output columns [32 wave, 32 wave + 32): A fragments gathered from the V rows
+    if (!pv_wave) return;
+    const int dv = 32 * wave + r;
+    const bool dv_ok = dv < d;
+    const unsigned char* vcol = smem + min(dv, d - 1) * 2;
+    f32x16 O;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) O[i] = 0.f;
+    float l = 0.f;
+    for (int t = 0; t < P.nkt; ++t) {
+        l += sm_l[t * 32 + r];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            unsigned w[4];
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                const int j = 2 * jp;
+                const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);     // j and j+1 are adjacent keys
+                const unsigned lo = *(const unsigned short*)(vcol + key * vst);
+                const unsigned hi = *(const unsigned short*)(vcol + (key + 1) * vst);
+                w[jp] = dv_ok ? (lo | (hi << 16)) : 0u;
+            }
+            u32x4 vfrag = {w[0], w[1], w[2], w[3]};
+            O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vfrag), as_bf16x8(sm_p[(t * 2 + s2) * 64 + lane]), O, 0, 0, 0);
+        }
+    }
+    const int q = qt * 32 + r;
+    if (q >= P.Nq) return;
+    const float inv = 1.0f / l;
+    const size_t obase = ((size_t)b * P.Nq + q) * P.H * d + (size_t)h * d;
+    const bool ovec = !P.out_bf16 && (d & 3) == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int dv0 = 32 * wave + 8 * g + 4 * hh;
+        if (ovec) {
+            if (dv0 < d) {
+                f32x4 o = {O[4 * g] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
+                *(f32x4*)((float*)P.out + obase + dv0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (dv0 + e < d) {
+                    const float val = O[4 * g + e] * inv;
+                    if (P.out_bf16) ((__bf16*)P.out)[obase + dv0 + e] = (__bf16)val;
+                    else ((float*)P.out)[obase + dv0 + e] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int DKS, int MODE>
+int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream) {
+    // V row stride in bytes: 16-byte multiple whose bank offset between the two lane halves
+    // (rows 4 apart) clears the 16 banks one half covers
+    int vst = (2 * p.d + 15) / 16 * 16;
+    while (vst % 64 < 16 || vst % 64 > 48) vst += 16;
+    const size_t images = std::max((size_t)(p.nkt + 1) * 2 * DKS * kUnit, (size_t)p.nkt * 32 * vst);
+    const size_t p_off = (images + 255) / 256 * 256;
+    const size_t st_off = p_off + (size_t)kSmallMaxTiles * 2 * 1024;
+    const size_t lds = st_off + 2 * kSmallMaxTiles * 32 * sizeof(float);
+    auto kern = small_attn_lds_kernel<DKS, MODE>;
+    static bool done = false;     // one device per process: the attribute is set once per instance
+    if (!done) {
+        SID_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(BH * p.NQT)), dim3(waves * 64), lds, stream, p, vst, (int)p_off, (int)st_off);
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}
+
 template <int DKS, int NKT, bool X3>
 int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStream_t stream) {
     const dim3 grid((unsigned)(BH * p.NQT)), block(waves * 64);
@@ -264,7 +516,11 @@ int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStre
         return ((uintptr_t)ptr & 15) == 0 && a % m == 0 && b % m == 0 && c % m == 0;
     };
     const int m = bf16in ? 8 : 4;
-    const bool vec = p.d % m == 0 && al(p.q, p.qsb, p.qsh, p.qsn, m) && al(p.k, p.ksb, p.ksh, p.ksn, m);
+    const bool vec = p.d % m == 0 && al(p.q, p.qsb, p.qsh, p.qsn, m) && al(p.k, p.ksb, p.ksh, p.ksn, m) &&
+                     ((uintptr_t)p.v & 15) == 0;
+    const char* e = getenv("SID_TUNE_SMALL_DIRECT");       // measurement and tests only
+    if (!X3 && vec && !(e && e[0] == '1'))
+        return bf16in ? launch_small_lds<DKS, 2>(p, BH, waves, stream) : launch_small_lds<DKS, 1>(p, BH, waves, stream);
     if (bf16in) {
         if (vec) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 2>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 0>), grid, block, 0, stream, p);

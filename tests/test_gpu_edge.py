@@ -125,9 +125,13 @@ def test_forced_key_splits_and_workgroup_widths(ks, nw, monkeypatch):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Nq,Nk,d,layout", [(2, 256, 256, 160, "bnhd"), (3, 64, 64, 160, "bhnd"), (1, 70, 200, 20, "bnhd"),
                                               (2, 40, 256, 100, "bhnd"), (1, 256, 129, 8, "bnhd")])
-def test_short_sequence_kernel(B, Nq, Nk, d, layout, dtype, compute):
+@pytest.mark.parametrize("staging", ["lds", "direct"])
+def test_short_sequence_kernel(B, Nq, Nk, d, layout, dtype, compute, staging, monkeypatch):
     """The single-launch kernel at the UNet's 16x16 / 8x8 self-attention shapes, with batches, both
-    layouts, both storage types and head dims the general path has no instance for."""
+    layouts, both storage types and head dims the general path has no instance for; both of its
+    operand staging variants (coalesced copies through LDS / direct fragment loads)."""
+    if staging == "direct":
+        monkeypatch.setenv("SID_TUNE_SMALL_DIRECT", "1")
     H = 8
     mk = lambda seed, n: torch.from_numpy(synth.normal(seed, (B, n, H * d))).to(dtype)
     q, k, v = mk(4450, Nq), mk(4451, Nk), mk(4452, Nk)
