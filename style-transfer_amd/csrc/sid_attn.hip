@@ -28,6 +28,16 @@ namespace {
 using namespace sid_attn;
 
 constexpr int kMaxJobs = 8;
+constexpr float LOG2E = 1.4426950408889634f;
+
+// The query images are multiplied by the logit scale, and the raw q.k extremes that the mask bias
+// needs are recovered by dividing it out again, so it must not be zero.  A scale of zero (T = 0)
+// becomes 2^-40: the logits it leaves (|q.k| * 1e-12) change no result, and a power of two keeps
+// the recovered extremes exact.
+inline float clamp_scale(float c) {
+    const float tiny = 9.094947017729282e-13f;   // 2^-40
+    return std::fabs(c) < tiny ? (std::signbit(c) ? -tiny : tiny) : c;
+}
 
 __device__ __forceinline__ u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
 
@@ -46,6 +56,8 @@ struct PackJob {
     u32x4* dst_lo;      // lo part in split mode, else null
     long long sb, sh, sn, sb2, sh2, sn2;
     float c1, c2;       // value = src*c1 + src2*c2 when src2 != null, else src
+    float post;         // then value *= post (query images carry the logit scale); 1 = none
+    int ones_at;        // row fragments: columns ones_at, ones_at+1 of every valid row are 1 (-1: none)
     int kind;           // 0: row fragments (Q, K)   1: transposed V fragments with ones column
     int vec4;           // kind 0, f32: every source row chunk is 16-byte aligned
     int N;              // valid rows
@@ -123,7 +135,12 @@ __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
                     }
                 }
             }
+            if (J.post != 1.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val[j] = __fmul_rn(val[j], J.post);
+            }
         }
+        if (row < J.N && d0 == J.ones_at) val[0] = val[1] = 1.f;
     } else {
         const int lane = (int)(gid & 63);
         const int hh = lane >> 5, r = lane & 31;
@@ -343,6 +360,10 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     if (w.bytes > workspace_bytes)
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
 
+    // logit scales in the log2 domain; applied to the query images by the pack kernel
+    const float c2s = clamp_scale(T * scale * LOG2E), c2c = clamp_scale(scale * LOG2E);
+    const bool shift_cols = d % 16 == 8 && d <= 72;      // head dims with a shifted-reference instance
+
     // ---- pack
     if (stg.pack) {
         PackParams pp = {};
@@ -352,17 +373,20 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
             PackJob& j = pp.job[i];
             j = PackJob{};
             j.src = src; j.dst = dst; j.dst_lo = dst_lo; j.kind = 0; j.N = N; j.NT = NT;
+            j.post = 1.f; j.ones_at = -1;
             set_strides(j, SID_LAYOUT_BHND, H, N, d, false);
             frags[i] = (long long)units;
         };
-        rowjob(0, q_cnt, w.q[0][0], w.q[0][1], g.NQT, g.q_units);      // blended query
-        pp.job[0].src2 = x_q; pp.job[0].c1 = gamma; pp.job[0].c2 = q_self_coef;
+        rowjob(0, q_cnt, w.q[0][0], w.q[0][1], g.NQT, g.q_units);      // blended query, in log2-logit units
+        pp.job[0].src2 = x_q; pp.job[0].c1 = gamma; pp.job[0].c2 = q_self_coef; pp.job[0].post = c2s;
         set_strides(pp.job[0], SID_LAYOUT_BNHD, H, N, d, true);
         rowjob(1, q_cnt, w.q[1][0], w.q[1][1], g.NQT, g.q_units);      // content query
+        pp.job[1].post = c2c;
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};
         for (int b = 0; b < kBlocks; ++b) {
             rowjob(2 + b, ks[b], w.k[b][0], w.k[b][1], g.NKT, g.k_units);
+            pp.job[2 + b].ones_at = shift_cols ? d : -1;
             rowjob(5 + b, vs[b], w.v[b][0], w.v[b][1], g.NKT, g.v_units);
             pp.job[5 + b].kind = 1;
         }
@@ -370,16 +394,16 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
         if (rc != SID_OK) return rc;
     }
     // ---- flash
-    constexpr float LOG2E = 1.4426950408889634f;
     FlashParams fp = {};
+    fp.shift_cols = shift_cols;
     for (int b = 0; b < kBlocks; ++b) {
         const int qi = (b == kBlocks - 1) ? 1 : 0;
         fp.q[b] = w.q[qi][0]; fp.q_lo[b] = w.q[qi][1];
         fp.k[b] = w.k[b][0]; fp.k_lo[b] = w.k[b][1];
         fp.v[b] = w.v[b][0]; fp.v_lo[b] = w.v[b][1];
     }
-    fp.c2[0] = fp.c2[1] = T * scale * LOG2E;
-    fp.c2[2] = scale * LOG2E;
+    fp.c2[0] = fp.c2[1] = c2s;
+    fp.c2[2] = c2c;
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
 }
 
@@ -421,6 +445,7 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     if (rc != SID_OK) return rc;
     Workspace w;
     carve(g, 1, 1, x3, (long long)B * H * Nq, d, workspace, &w);
+    const float c2p = clamp_scale(logit_scale * LOG2E);
     if (w.bytes > workspace_bytes)
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
 
@@ -432,20 +457,24 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
             PackJob& j = pp.job[i];
             j = PackJob{};
             j.src = src; j.dst = dst; j.dst_lo = dst_lo; j.kind = kind; j.N = N; j.NT = NT;
+            j.post = 1.f; j.ones_at = -1;
             set_strides(j, layout, H, N, d, false);
             frags[i] = (long long)units;
         };
         job(0, q, w.q[0][0], w.q[0][1], 0, Nq, g.NQT, g.q_units, q_layout);
+        pp.job[0].post = c2p;
         job(1, k, w.k[0][0], w.k[0][1], 0, Nk, g.NKT, g.k_units, kv_layout);
+        pp.job[1].ones_at = (d % 16 == 8 && d <= 72) ? d : -1;
         job(2, v, w.v[0][0], w.v[0][1], 1, Nk, g.NKT, g.v_units, kv_layout);
         rc = launch_pack(pp, frags, stream);
         if (rc != SID_OK) return rc;
     }
     FlashParams fp = {};
+    fp.shift_cols = d % 16 == 8 && d <= 72;
     fp.q[0] = w.q[0][0]; fp.q_lo[0] = w.q[0][1];
     fp.k[0] = w.k[0][0]; fp.k_lo[0] = w.k[0][1];
     fp.v[0] = w.v[0][0]; fp.v_lo[0] = w.v[0][1];
-    fp.c2[0] = logit_scale * LOG2E;
+    fp.c2[0] = c2p;
     return run_flash_merge(fp, g, w, stg, nullptr, out, 1.f, B, H, Nq, Nk, d, 1, dtype, x3, stream);
 }
 
@@ -454,38 +483,69 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
 // ------------------------------------------------------------------------------------------
 namespace sid_attn {
 
-// One thread per (row, VEC output columns).  The statistics of a row are re-read by the d/VEC
-// threads that share it; they are 16 bytes per part and stay in L1/L2.
-template <int VEC>
+// One thread per (row, VEC output columns), thread order (head, query, column): the reads, nparts
+// times the volume of the writes, are contiguous across the wave.  NP > 0 fixes the number of parts
+// at compile time: all statistics and all partial rows are then requested before the first one is
+// used (one memory round trip per thread instead of one per part).
+template <int VEC, int NP>
 __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const int dpv = P.d / VEC;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)P.B * P.H * P.Nq * dpv;
     if (gid >= total) return;
-    // thread order follows the PARTIALS (head, query, column): the reads, nparts times the volume of
-    // the writes, are contiguous across the wave
     const int c = (int)(gid % dpv);
     const long long t = gid / dpv;
     const int q = (int)(t % P.Nq);
     const int bh = (int)(t / P.Nq);
     const int b = bh / P.H, h = bh % P.H;
     const int BH = P.B * P.H;
-    const int nparts = P.nblk * P.KS;
+    const int nparts = NP > 0 ? NP : P.nblk * P.KS;
+    constexpr int CAP = NP > 0 ? NP : 1;
     constexpr float LOG2E = 1.4426950408889634f;
-    auto stat = [&](int p) { return *(const f32x4*)(P.stats + (((size_t)p * BH + bh) * P.Nq + q) * 4); };
+    auto stat_ptr = [&](int p) { return (const f32x4*)(P.stats + (((size_t)p * BH + bh) * P.Nq + q) * 4); };
+    auto part_ptr = [&](int p) { return P.opart + (((size_t)p * BH + bh) * P.Nq + q) * P.d + c * VEC; };
+
+    f32x4 st_[CAP];
+    float o_[CAP][VEC];
+    if (NP > 0) {
+#pragma unroll
+        for (int p = 0; p < CAP; ++p) st_[p] = *stat_ptr(p);
+#pragma unroll
+        for (int p = 0; p < CAP; ++p) {
+            if (VEC == 4) {
+                const f32x4 v = *(const f32x4*)part_ptr(p);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o_[p][e] = v[e % 4];
+            } else {
+                o_[p][0] = *part_ptr(p);
+            }
+        }
+    }
+    auto stat = [&](int p) { return NP > 0 ? st_[NP > 0 ? p : 0] : *stat_ptr(p); };
 
     float bias2[kBlocks] = {0.f, 0.f, 0.f};
     if (P.nblk == kBlocks) {
+        const int KS = nparts >= kBlocks ? nparts / kBlocks : 1;
         float bmax[kBlocks], cmin = SID_INF;
 #pragma unroll
-        for (int blk = 0; blk < kBlocks; ++blk) {
-            float mx = -SID_INF;
-            for (int ks = 0; ks < P.KS; ++ks) {
-                const f32x4 st = stat(blk * P.KS + ks);
-                mx = fmaxf(mx, st[2]);
+        for (int blk = 0; blk < kBlocks; ++blk) bmax[blk] = -SID_INF;
+        if (NP > 0) {
+#pragma unroll
+            for (int p = 0; p < CAP; ++p) {
+                const int blk = p / (CAP / kBlocks > 0 ? CAP / kBlocks : 1);
+                const f32x4 st = stat(p);
+#pragma unroll
+                for (int k = 0; k < kBlocks; ++k) bmax[k] = (k == blk) ? fmaxf(bmax[k], st[2]) : bmax[k];
                 if (blk == kBlocks - 1) cmin = fminf(cmin, st[3]);
             }
-            bmax[blk] = mx;
+        } else {
+            for (int p = 0; p < nparts; ++p) {
+                const int blk = p / KS;
+                const f32x4 st = stat(p);
+#pragma unroll
+                for (int k = 0; k < kBlocks; ++k) bmax[k] = (k == blk) ? fmaxf(bmax[k], st[2]) : bmax[k];
+                if (blk == kBlocks - 1) cmin = fminf(cmin, st[3]);
+            }
         }
         // min_j (q_cnt.k_cnt * scale): scaling by a constant is monotone, so it commutes with min
         const float min_cc = (P.scale >= 0.f) ? __fmul_rn(cmin, P.scale) : __fmul_rn(bmax[2], P.scale);
@@ -493,30 +553,51 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
         bias2[0] = __fmul_rn(__fsub_rn(min_cc, bmax[0]), __fmul_rn(m, -1.0f)) * LOG2E;
         bias2[1] = __fmul_rn(__fsub_rn(min_cc, bmax[1]), __fmul_rn(m, 1.0f)) * LOG2E;
     }
+    const int KSr = P.KS;
+    auto blk_of = [&](int p) { return p / KSr; };
+    auto bias_of = [&](int p) { const int k = blk_of(p); return k == 0 ? bias2[0] : (k == 1 ? bias2[1] : bias2[2]); };
+    auto c2_of = [&](int p) { const int k = blk_of(p); return k == 0 ? P.c2[0] : (k == 1 ? P.c2[1] : P.c2[2]); };
     // reference of the combined softmax: the largest biased logit of the row (the true maxima, not
     // the parts' own references, which a logit may exceed by up to 2^kOverflowThr)
     float M2 = -SID_INF;
-    for (int p = 0; p < nparts; ++p) {
-        const f32x4 st = stat(p);
-        const float cp = P.c2[p / P.KS];
-        if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias2[p / P.KS]);
-    }
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     float den = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        const f32x4 st = stat(p);
-        if (!(st[1] > 0.f)) continue;
-        const float w = __builtin_amdgcn_exp2f(st[0] + bias2[p / P.KS] - M2);
-        den += w * st[1];
-        const float* op = P.opart + (((size_t)p * BH + bh) * P.Nq + q) * P.d + c * VEC;
-        if (VEC == 4) {
-            const f32x4 o = *(const f32x4*)op;
+    if (NP > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += w * o[e];
-        } else {
-            acc[0] += w * op[0];
+        for (int p = 0; p < CAP; ++p) {
+            const f32x4 st = stat(p);
+            const float cp = c2_of(p);
+            if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias_of(p));
+        }
+#pragma unroll
+        for (int p = 0; p < CAP; ++p) {
+            const f32x4 st = stat(p);
+            const float w = st[1] > 0.f ? __builtin_amdgcn_exp2f(st[0] + bias_of(p) - M2) : 0.f;
+            den += w * (st[1] > 0.f ? st[1] : 0.f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] += w * o_[p][e];
+        }
+    } else {
+        for (int p = 0; p < nparts; ++p) {
+            const f32x4 st = stat(p);
+            const float cp = c2_of(p);
+            if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias_of(p));
+        }
+        for (int p = 0; p < nparts; ++p) {
+            const f32x4 st = stat(p);
+            if (!(st[1] > 0.f)) continue;
+            const float w = __builtin_amdgcn_exp2f(st[0] + bias_of(p) - M2);
+            den += w * st[1];
+            const float* op = part_ptr(p);
+            if (VEC == 4) {
+                const f32x4 o = *(const f32x4*)op;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += w * o[e % 4];
+            } else {
+                acc[0] += w * op[0];
+            }
         }
     }
     const float inv = 1.0f / den;
@@ -528,7 +609,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     } else {
         float* o = (float*)P.out + oidx;
         if (VEC == 4) {
-            f32x4 r = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+            f32x4 r = {acc[0] * inv, acc[VEC > 1 ? 1 : 0] * inv, acc[VEC > 2 ? 2 : 0] * inv, acc[VEC > 3 ? 3 : 0] * inv};
             *(f32x4*)o = r;
         } else {
             o[0] = acc[0] * inv;
@@ -536,12 +617,23 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     }
 }
 
+template <int VEC>
+void launch_merge_np(const MergeParams& mp, unsigned blocks, hipStream_t stream) {
+    switch (mp.nblk * mp.KS) {
+        case 2: hipLaunchKernelGGL((merge_kernel<VEC, 2>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        default: hipLaunchKernelGGL((merge_kernel<VEC, 0>), dim3(blocks), dim3(256), 0, stream, mp); break;
+    }
+}
+
 int launch_merge(const MergeParams& mp, hipStream_t stream) {
     const int vec = (mp.d & 3) == 0 ? 4 : 1;
     const long long total = (long long)mp.B * mp.H * mp.Nq * (mp.d / vec);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (vec == 4) hipLaunchKernelGGL(merge_kernel<4>, dim3(blocks), dim3(256), 0, stream, mp);
-    else hipLaunchKernelGGL(merge_kernel<1>, dim3(blocks), dim3(256), 0, stream, mp);
+    if (vec == 4) launch_merge_np<4>(mp, blocks, stream);
+    else launch_merge_np<1>(mp, blocks, stream);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
 }

@@ -42,7 +42,9 @@ struct FlashParams {
     const u32x4* k_lo[kBlocks];
     const u32x4* v[kBlocks];
     const u32x4* v_lo[kBlocks];
-    float c2[kBlocks];           // logit scale of each block, log2 domain: x = (q.k) * c2
+    float c2[kBlocks];           // logit scale of each block, log2 domain: x = (q.k) * c2; already applied to
+                                 // the packed query images, never zero (the host clamps |c2| >= 2^-40)
+    int shift_cols;              // head_dim % 16 == 8: key images carry ones in columns d, d+1
     float* opart;                // [part][BH][Nq][d] un-normalised partial outputs
     float* stats;                // [part][BH][Nq][4] = (m2, l, smax, smin)
     void* out;                   // (B, Nq, H*d), written here only when direct != 0
@@ -111,12 +113,22 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Logits reach the kernel already in the log2 domain: the pack kernel multiplies the query image by
+// c2 = logit_scale * log2(e), so x = K.Q' needs no multiply.
 struct RowState {
-    float m2;      // log2-domain reference the exponentials are taken against
-    float smax;    // running max of the raw q.k (this lane half's keys)
+    float m2;      // reference the exponentials are taken against
+    float smax;    // running max of x (this lane half's keys)
     float smin;    // running min (tracked only where needed)
-    float ovf;     // largest (logit - m2) seen while m2 was held fixed
 };
+
+// How a tile's exponentials are referenced:
+//   kOnline : exact online softmax; m2 follows the running row max and O is rescaled every tile
+//             (first stage, tail stages, and the fallback pass)
+//   kFixed  : m2 frozen, p = exp2(x - m2)
+//   kShifted: m2 frozen AND already subtracted by the MFMA itself: two spare (zero-padding) columns of
+//             the query fragments hold -m2 as a bf16 pair and the key image holds ones there, so the
+//             accumulator is x - m2 and p = exp2(S) with no VALU arithmetic in front of the exponential
+enum { kOnline = 0, kFixed = 1, kShifted = 2 };
 
 __device__ __forceinline__ float max16(const f32x16& S) {
     float t = fmaxf(fmaxf(S[0], S[1]), S[2]);
@@ -164,15 +176,11 @@ __device__ __forceinline__ f32x16 qk_tile(const Frags<DKS, X3>& kf, const Frags<
 }
 
 // Softmax step for one 32x32 tile whose logits S are ready, then O^T += V^T P^T.
-//   RESCALE = true : exact online softmax, the reference m2 follows the running row max and O is
-//                    rescaled every tile (first stage, tail stages, and the fallback pass).
-//   RESCALE = false: m2 stays fixed; the block only records how far a logit exceeded it.  The
-//                    body is then straight-line code: max, fma, exp2, cvt, MFMA.
-//   TAIL           : keys >= Nk are masked.
+//   TAIL: keys >= Nk are masked (only with kOnline).
 // vf holds the V^T fragments of the tile: index s2 * DVB + b (k-step s2, dv block b).
-template <int DVB, bool X3, bool TAIL, bool TRACK_MIN, bool RESCALE>
+template <int DVB, bool X3, bool TAIL, bool TRACK_MIN, int MODE>
 __device__ __forceinline__ void softmax_pv_tile(const f32x16& S, const Frags<2 * DVB, X3>& vf, int hh, int key0,
-                                                int Nk, float c2, f32x16 (&O)[DVB], RowState& rs) {
+                                                int Nk, f32x16 (&O)[DVB], RowState& rs) {
     float tmax, tmin = SID_INF;
     if (!TAIL) {
         tmax = max16(S);
@@ -186,12 +194,12 @@ __device__ __forceinline__ void softmax_pv_tile(const f32x16& S, const Frags<2 *
             tmin = ok ? fminf(tmin, S[i]) : tmin;
         }
     }
-    rs.smax = fmaxf(rs.smax, tmax);
-    if (TRACK_MIN || TAIL) rs.smin = fminf(rs.smin, tmin);
+    // the statistics stay in unshifted coordinates
+    rs.smax = fmaxf(rs.smax, MODE == kShifted ? tmax + rs.m2 : tmax);
+    if (TRACK_MIN || TAIL) rs.smin = fminf(rs.smin, MODE == kShifted ? tmin + rs.m2 : tmin);
 
-    const float tref = (c2 >= 0.f) ? tmax * c2 : tmin * c2;     // -inf where this half has no valid key
-    if (RESCALE) {
-        const float full = fmaxf(tref, __shfl_xor(tref, 32));
+    if (MODE == kOnline) {
+        const float full = fmaxf(tmax, __shfl_xor(tmax, 32));       // -inf where neither half has a valid key
         const float mnew = fmaxf(rs.m2, full);
         const float alpha = (mnew == -SID_INF) ? 1.f : __builtin_amdgcn_exp2f(rs.m2 - mnew);
 #pragma unroll
@@ -199,14 +207,12 @@ __device__ __forceinline__ void softmax_pv_tile(const f32x16& S, const Frags<2 *
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[b][i] *= alpha;
         rs.m2 = mnew;
-    } else {
-        rs.ovf = fmaxf(rs.ovf, tref - rs.m2);
     }
     const float m2 = rs.m2;
 
     float pv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[i], c2, -m2));
+    for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(MODE == kShifted ? S[i] : S[i] - m2);
     if (TAIL) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -239,8 +245,8 @@ __device__ __forceinline__ void softmax_pv_tile(const f32x16& S, const Frags<2 *
 // One LDS stage of KVS key tiles for the wave's QT query tiles.  Per key tile the K and V fragments
 // are read from LDS once and feed the MFMAs of all QT query tiles; the QT independent softmax
 // chains give the scheduler VALU work to run beside the matrix pipe.
-template <int DKS, int DVB, int KVS, bool X3, int QT, bool TAIL, bool TRACK_MIN, bool RESCALE>
-__device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, int key0, int Nk, float c2,
+template <int DKS, int DVB, int KVS, bool X3, int QT, bool TAIL, bool TRACK_MIN, int MODE>
+__device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, int key0, int Nk,
                                               const Frags<DKS, X3> (&qf)[QT], f32x16 (&O)[QT][DVB],
                                               RowState (&rs)[QT]) {
     constexpr int KU = KVS * DKS * 64;
@@ -257,7 +263,10 @@ __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, 
         for (int t = 0; t < QT; ++t) S[t] = qk_tile<DKS, X3>(kf, qf[t]);
 #pragma unroll
         for (int t = 0; t < QT; ++t)
-            softmax_pv_tile<DVB, X3, TAIL, TRACK_MIN, RESCALE>(S[t], vf, hh, key0 + 32 * j, Nk, c2, O[t], rs[t]);
+            softmax_pv_tile<DVB, X3, TAIL, TRACK_MIN, MODE>(S[t], vf, hh, key0 + 32 * j, Nk, O[t], rs[t]);
+        // keep the tiles of a stage apart in the schedule: the QT query tiles already give the matrix
+        // and vector pipes independent work, and overlapping two key tiles as well costs registers
+        if (QT > 1 && j + 1 < KVS) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -275,7 +284,9 @@ __device__ __forceinline__ void glds16(const u32x4* src_uniform, unsigned lane_b
 }
 __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int DKS, int DVB, int KVS, bool X3, int QT, int NW>
+// SHIFT: the kShifted steady state (head_dim % 16 == 8); a separate instance rather than a run-time
+// branch, because a kernel that carries both steady-state loops no longer fits its registers.
+template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT>
 __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     constexpr int KU = KVS * DKS * 64;        // u32x4 per stage: K image
@@ -360,8 +371,9 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
 
     // Stages [it0, it1) of this part with ONE variant of the stage body per loop, so that every loop
     // is straight-line code.
-    auto run = [&](auto tail_c, auto min_c, auto resc_c, int it0, int it1) {
-        constexpr bool TAIL = decltype(tail_c)::value, TMIN = decltype(min_c)::value, RESC = decltype(resc_c)::value;
+    auto run = [&](auto tail_c, auto min_c, auto mode_c, int it0, int it1) {
+        constexpr bool TAIL = decltype(tail_c)::value, TMIN = decltype(min_c)::value;
+        constexpr int MODE = decltype(mode_c)::value;
         for (int it = it0; it < it1; ++it) {
             // Nothing the compiler counts may be outstanding once the direct loads are in flight: its
             // counted vmcnt waits do not know about them and would wait for the oldest one in every
@@ -369,22 +381,33 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             // this wait is free; it only resets the compiler's bookkeeping.
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             if (it + 1 < P.SPS) issue_stage(st0 + it + 1, (it + 1) & 1);
-            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, RESC>(lds + (it & 1) * SU, lane, hh,
-                                                                   (st0 + it) * KVS * 32, P.Nk, c2, qf, O, rs);
+            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE>(lds + (it & 1) * SU, lane, hh,
+                                                                   (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
             wait_direct_loads();
             __syncthreads();          // stage it+1 has landed in every wave's view; stage it is free
         }
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
+    using Online = std::integral_constant<int, kOnline>;
+    using Fixed = std::integral_constant<int, kFixed>;
+    using Shifted = std::integral_constant<int, kShifted>;
+
+    // The spare columns d, d+1 of the query fragments (zero padding when head_dim % 16 == 8; the key
+    // image holds ones there): dword 0 of the last k-step in the upper lane half.
+    auto set_shift = [&](int t, unsigned pair) {
+        u32x4 w = __builtin_bit_cast(u32x4, qf[t].hi[DKS - 1]);
+        w[0] = hh ? pair : w[0];
+        qf[t].hi[DKS - 1] = as_bf16x8(w);
+    };
 
     // stages of this part that hold only valid keys (every part runs SPS stages; the rest are tails)
     const int nfull = max(0, min(P.SPS, P.Nk / (KVS * 32) - st0));
 
-    // Pass 0 holds the softmax reference fixed after the first stage (no rescaling in the loop) and
-    // records the largest excess over it.  If some row of the workgroup exceeded the safe range
-    // (data whose logits grow by more than 2^96 along the keys), pass 1 redoes the workgroup with
-    // the exact online rescale in every tile.
+    // Pass 0 holds the softmax reference fixed after the first stage (no rescaling in the loop).  If
+    // afterwards some row of the workgroup turns out to have exceeded its reference by more than
+    // 2^kOverflowThr (logits that grow that much along the keys), pass 1 redoes the workgroup with the
+    // exact online rescale in every tile.
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -392,24 +415,49 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             for (int b = 0; b < DVB; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) O[t][b][i] = 0.f;
-            rs[t].m2 = -SID_INF; rs[t].smax = -SID_INF; rs[t].smin = SID_INF; rs[t].ovf = -SID_INF;
+            rs[t].m2 = -SID_INF; rs[t].smax = -SID_INF; rs[t].smin = SID_INF;
         }
         issue_stage(st0, 0);
         wait_direct_loads();
         __syncthreads();
 
         if (pass == 0) {
-            run(F_{}, T_{}, T_{}, 0, min(1, nfull));                  // first stage: exact running max
-            if (need_min) run(F_{}, T_{}, F_{}, 1, nfull);            // steady state, fixed reference
-            else run(F_{}, F_{}, F_{}, 1, nfull);
+            run(F_{}, T_{}, Online{}, 0, min(1, nfull));              // first stage: exact running max
+            if (nfull > 1) {
+                if constexpr (SHIFT) {
+                    // freeze the reference at a value two bf16 represent exactly and hand it to the MFMA
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const __bf16 h1 = (__bf16)(-rs[t].m2);
+                        const __bf16 h2 = (__bf16)(-rs[t].m2 - (float)h1);
+                        const float m2r = -((float)h1 + (float)h2);
+                        const float adj = __builtin_amdgcn_exp2f(rs[t].m2 - m2r);
+#pragma unroll
+                        for (int b = 0; b < DVB; ++b)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) O[t][b][i] *= adj;
+                        rs[t].m2 = m2r;
+                        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                        bf16x2 pr = {h1, h2};
+                        set_shift(t, __builtin_bit_cast(unsigned, pr));
+                    }
+                    if (need_min) run(F_{}, T_{}, Shifted{}, 1, nfull);
+                    else run(F_{}, F_{}, Shifted{}, 1, nfull);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) set_shift(t, 0u);
+                } else {
+                    if (need_min) run(F_{}, T_{}, Fixed{}, 1, nfull);
+                    else run(F_{}, F_{}, Fixed{}, 1, nfull);
+                }
+            }
         } else {
-            run(F_{}, T_{}, T_{}, 0, nfull);
+            run(F_{}, T_{}, Online{}, 0, nfull);
         }
-        run(T_{}, T_{}, T_{}, nfull, P.SPS);                          // stages with masked keys
+        run(T_{}, T_{}, Online{}, nfull, P.SPS);                      // stages with masked keys
 
         bool over = false;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) over |= rs[t].ovf > kOverflowThr;
+        for (int t = 0; t < QT; ++t) over |= rs[t].smax - rs[t].m2 > kOverflowThr;
         if (pass == 0 && __any(over) && lane == 0) redo = 1;
         __syncthreads();
         if (pass == 1 || redo == 0) break;
@@ -420,8 +468,12 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     const bool vec = (d & 3) == 0;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const float smax = fmaxf(rs[t].smax, __shfl_xor(rs[t].smax, 32));
-        const float smin = fminf(rs[t].smin, __shfl_xor(rs[t].smin, 32));
+        // raw q.k extremes from the log2-domain ones: x = c2 * (q.k)
+        const float xmax = fmaxf(rs[t].smax, __shfl_xor(rs[t].smax, 32));
+        const float xmin = fminf(rs[t].smin, __shfl_xor(rs[t].smin, 32));
+        const float inv_c2 = 1.0f / c2;
+        const float smax = (c2 > 0.f ? xmax : xmin) * inv_c2;
+        const float smin = (c2 > 0.f ? xmin : xmax) * inv_c2;
         // softmax denominator = the ones column = row 31 of the last dv block = register 15, half 1
         float lsum = hh ? O[t][DVB - 1][15] : 0.f;
         lsum += __shfl_xor(lsum, 32);
@@ -481,11 +533,11 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     }
 }
 
-template <int DKS, int DVB, bool X3, int NW>
+template <int DKS, int DVB, bool X3, int NW, bool SHIFT>
 int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     constexpr int KVS = stage_tiles(DKS, DVB, X3);
     constexpr int QT = query_tiles(DKS, DVB, X3);
-    auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW>;
+    auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT>;
     if (g.lds > 48 * 1024) {
         static bool done = false;   // one device per process: the attribute is set once per instance
         if (!done) {
@@ -499,18 +551,27 @@ int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stre
     return SID_OK;
 }
 
+template <int DKS, int DVB, bool X3, bool SHIFT>
+int launch_flash_nw(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
+    switch (g.NW) {
+        case 4: return launch_flash_inst<DKS, DVB, X3, 4, SHIFT>(fp, g, stream);
+        case 2: return launch_flash_inst<DKS, DVB, X3, 2, SHIFT>(fp, g, stream);
+        default: return launch_flash_inst<DKS, DVB, X3, 1, SHIFT>(fp, g, stream);
+    }
+}
+
 template <bool X3>
 int launch_flash(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
-#define SID_CASE(a, b)                                                                   \
-    if (g.DKS == a && g.DVB == b) {                                                      \
-        switch (g.NW) {                                                                  \
-            case 4: return launch_flash_inst<a, b, X3, 4>(fp, g, stream);                \
-            case 2: return launch_flash_inst<a, b, X3, 2>(fp, g, stream);                \
-            default: return launch_flash_inst<a, b, X3, 1>(fp, g, stream);               \
-        }                                                                                \
+    // (DKS, DVB) pairs that contain a head_dim with head_dim % 16 == 8 also have a SHIFT instance
+#define SID_CASE(a, b, has_shift)                                                                            \
+    if (g.DKS == a && g.DVB == b) {                                                                          \
+        if constexpr (has_shift) {                                                                           \
+            if (fp.shift_cols) return launch_flash_nw<a, b, X3, true>(fp, g, stream);                        \
+        }                                                                                                    \
+        return launch_flash_nw<a, b, X3, false>(fp, g, stream);                                              \
     }
-    SID_CASE(2, 1) SID_CASE(2, 2) SID_CASE(3, 2) SID_CASE(4, 2) SID_CASE(4, 3) SID_CASE(5, 3)
-    SID_CASE(6, 4) SID_CASE(8, 5) SID_CASE(10, 6)
+    SID_CASE(2, 1, true) SID_CASE(2, 2, false) SID_CASE(3, 2, true) SID_CASE(4, 2, true) SID_CASE(4, 3, false)
+    SID_CASE(5, 3, true) SID_CASE(6, 4, false) SID_CASE(8, 5, false) SID_CASE(10, 6, false)
 #undef SID_CASE
     return sid::fail(SID_ENOSYS, "no flash kernel for DKS=%d DVB=%d", g.DKS, g.DVB);
 }
