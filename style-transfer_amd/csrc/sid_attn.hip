@@ -208,9 +208,11 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, Geomet
     if (const char* e = getenv("SID_TUNE_NW")) nw = atoi(e);
     g->NW = nw;
     g->nQG = (qwaves + nw - 1) / nw;
-    // key splits: until there are >= 2 workgroups per CU, while every split keeps a few stages
+    // key splits: until there are >= 2 workgroups per CU, while every split keeps enough stages to
+    // amortise a workgroup's fixed cost and the partials it adds to the merge (measured: splitting
+    // pays from about 16 stages per split)
     int ks = 1;
-    while (ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 4) ++ks;
+    while (ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 16) ++ks;
     if (const char* e = getenv("SID_TUNE_KS")) ks = atoi(e);
     g->SPS = (stages + ks - 1) / ks;
     g->KS = (stages + g->SPS - 1) / g->SPS;               // drop splits that would hold no key
