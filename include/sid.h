@@ -131,6 +131,17 @@ int sid_hf_filter(const void* h_cnt, const void* skip, const void* h, void* out,
 int sid_hf_filter_radius(const void* h_cnt, const void* skip, const void* h, void* out,
                          int B, int C, int H, int W, int radius, int dtype, void* stream);
 
+/*
+ * Masked AdaIN initial latent.
+ * Replaces run_ori.py:77-82 (adain: per-channel mean / unbiased std over (batch, H, W)) and
+ * run_ori.py:228-232 (bilinear resize of the raw [0,1] mask to the latent size, no threshold;
+ * out = m * adain(cnt, char) + (1 - m) * adain(cnt, back)).
+ *   cnt, sty_char, sty_back, out (B, C, H, W);  mask (Hin, Win) f32 on the device.
+ *   mask == NULL and sty_back == NULL: out = adain(cnt, sty_char), the single-style form.
+ */
+int sid_masked_adain(const void* cnt, const void* sty_char, const void* sty_back, const float* mask,
+                     int Hin, int Win, void* out, int B, int C, int H, int W, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

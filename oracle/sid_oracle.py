@@ -266,3 +266,26 @@ def make_ddim_timesteps_uniform(num_ddim, num_ddpm=1000):
     """ldm/modules/diffusionmodules/util.py:46-60, 'uniform' method: arange(num_ddim)*c + 1."""
     c = num_ddpm // num_ddim
     return (np.arange(0, num_ddim) * c).astype(int) + 1
+
+
+# --------------------------------------------------------------------------------------
+# Masked AdaIN initial latent                      run_ori.py:77-82, 228-232
+# --------------------------------------------------------------------------------------
+def adain(cnt, sty):
+    """((cnt - mean_c)/std_c)*std_s + mean_s, statistics per channel over (batch, H, W), std unbiased
+    (torch.std default)                                                   run_ori.py:77-82"""
+    c, s = np.asarray(cnt, F32), np.asarray(sty, F32)
+    ax = (0, 2, 3)
+    cm, sm_ = c.mean(ax, keepdims=True, dtype=np.float64), s.mean(ax, keepdims=True, dtype=np.float64)
+    cs, ss = c.std(ax, keepdims=True, ddof=1, dtype=np.float64), s.std(ax, keepdims=True, ddof=1, dtype=np.float64)
+    cm, sm_, cs, ss = (a.astype(F32) for a in (cm, sm_, cs, ss))
+    return ((((c - cm).astype(F32) / cs).astype(F32) * ss).astype(F32) + sm_).astype(F32)
+
+
+def masked_adain_init(cnt, char, back, mask):
+    """m*adain(cnt,char) + (1-m)*adain(cnt,back), m = bilinear resize of the RAW mask (no threshold)
+    to the latent size                                                    run_ori.py:228-232"""
+    H, W = cnt.shape[2], cnt.shape[3]
+    m = bilinear_resize(np.asarray(mask, F32), H, W)[None, None]
+    a, b = adain(cnt, char), adain(cnt, back)
+    return ((m * a).astype(F32) + ((F32(1.0) - m).astype(F32) * b).astype(F32)).astype(F32)

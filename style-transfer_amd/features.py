@@ -36,3 +36,19 @@ def feat_merge_2sty(opt, cnt_feats, sty_feats_1, sty_feats_2, start_step=0):
             if is_q or is_kv:
                 step[key + '_sty2'] = sty2[key]
     return merged
+
+
+def adain(cnt_feat, sty_feat):
+    """((cnt - mean_c) / std_c) * std_s + mean_s per channel over (batch, H, W), unbiased std
+    (run_ori.py:77-82), in one kernel."""
+    from . import ops
+    return ops.masked_adain(cnt_feat.contiguous(), sty_feat.contiguous())
+
+
+def masked_adain_init(cnt_z_enc, char_z_enc, back_z_enc, mask):
+    """Initial latent of the two-style sampler (run_ori.py:228-232): the raw [0,1] content mask
+    (H0, W0), resized bilinearly to the latent, blends adain(cnt, char) and adain(cnt, back)."""
+    import torch
+    from . import ops
+    m = torch.as_tensor(mask, dtype=torch.float32, device=cnt_z_enc.device).contiguous()
+    return ops.masked_adain(cnt_z_enc.contiguous(), char_z_enc.contiguous(), back_z_enc.contiguous(), m)

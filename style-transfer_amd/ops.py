@@ -154,3 +154,30 @@ def hf_filter(h_cnt, ratio=0.5, skip=None, h=None, out=None):
                                           h.data_ptr() if h is not None else None, out.data_ptr(),
                                           B, C, Hh, Ww, radius, _dtype_code(h_cnt), _stream(dev)))
     return out
+
+
+def masked_adain(cnt, sty_char, sty_back=None, mask=None, out=None):
+    """m * adain(cnt, sty_char) + (1 - m) * adain(cnt, sty_back) with m the raw (Hin, Win) float32 mask
+    resized bilinearly to the latent; with sty_back and mask None: adain(cnt, sty_char).  (B,C,H,W)."""
+    L = _lib.load()
+    ts = [cnt, sty_char] + ([sty_back] if sty_back is not None else [])
+    dev = _need_cuda(*ts)
+    if (sty_back is None) != (mask is None):
+        raise ValueError("sty_back and mask go together")
+    for t in ts:
+        if tuple(t.shape) != tuple(cnt.shape) or t.dtype != cnt.dtype or t.dim() != 4:
+            raise ValueError("latents must share one (B,C,H,W) shape and dtype")
+    if mask is not None:
+        _need_cuda(mask)
+        if mask.dtype != torch.float32 or mask.dim() != 2 or mask.device != dev:
+            raise ValueError("mask must be a 2-D float32 tensor on the latents' device")
+    B, C, H, W = cnt.shape
+    if out is None:
+        out = torch.empty_like(cnt)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_masked_adain(cnt.data_ptr(), sty_char.data_ptr(),
+                                      sty_back.data_ptr() if sty_back is not None else None,
+                                      mask.data_ptr() if mask is not None else None,
+                                      mask.shape[0] if mask is not None else 0, mask.shape[1] if mask is not None else 0,
+                                      out.data_ptr(), B, C, H, W, _dtype_code(cnt), _stream(dev)))
+    return out

@@ -260,8 +260,45 @@ def gen_feat_merge():
     print("feat_merge: steps", {k: sum(len(d) > 1 for d in v) for k, v in out.items()})
 
 
+def gen_adain():
+    """`adain` is compiled from run_ori.py's syntax tree (the file itself cannot be imported here); the
+    mask blend of run_ori.py:228-232 is restated with the same torch calls on real masks and seeded
+    latents.  Fixture: the blended initial latents and the plain adain outputs."""
+    import ast
+    import torch
+    import torch.nn.functional as F
+    from style_transfer_amd import synth
+    src = open(os.path.join(REF, "run_ori.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "adain"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "run_ori.py", "exec"), ns)
+    adain = ns["adain"]
+    masks = np.load(os.path.join(HERE, "masks_packed.npz"))
+    out, cases = {}, []
+    names = sorted(masks.files)[:3]
+    for ci, (shape, mname, sig) in enumerate([((1, 4, 64, 64), names[0], 1.0), ((1, 4, 64, 64), names[1], 3.0),
+                                              ((2, 4, 32, 32), names[2], 1.0), ((1, 8, 16, 48), names[0], 0.5)]):
+        bits = np.unpackbits(masks[mname]).reshape(512, 512).astype(np.float32)
+        seeds = [7000 + 10 * ci + j for j in range(3)]
+        cnt, char, back = (torch.from_numpy(synth.normal(sd, shape, sigma=sig) + np.float32(0.3 * j))
+                           for j, sd in enumerate(seeds))
+        m = torch.tensor(bits, dtype=torch.float32).unsqueeze(0).unsqueeze(0)
+        m = F.interpolate(m, size=(shape[2], shape[3]), mode="bilinear", align_corners=False)
+        m = m.expand(-1, shape[1], -1, -1)
+        blended = m * adain(cnt, char) + (1 - m) * adain(cnt, back)
+        out[f"blend/{ci}"] = blended.numpy()
+        out[f"adain/{ci}"] = adain(cnt, char).numpy()
+        cases.append({"id": ci, "shape": list(shape), "mask": mname, "sigma": sig, "seeds": seeds})
+    np.savez_compressed(os.path.join(HERE, "adain.npz"), **out)
+    with open(os.path.join(HERE, "adain_cases.json"), "w") as f:
+        json.dump(cases, f)
+    print("adain:", len(cases), "cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge"]
+    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain"]
+    if "adain" in which:
+        gen_adain()
     if "feat_merge" in which:
         gen_feat_merge()
     if "masks" in which:

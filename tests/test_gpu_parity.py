@@ -200,3 +200,23 @@ def test_gen_pkl_mode_exposes_features():
         out = mod(x)[0].cpu().numpy()
     assert rel_err(out[np.array(case["rows"])], gold[f"out_rows/{case['id']}"]) < 1e-4
     assert tuple(mod.q.shape) == (H, N, d) and tuple(mod.qk_sim.shape) == (H, N, N) and mod.attn is not None
+
+
+def test_masked_adain_init_vs_reference_golden():
+    """Initial latent m*adain(cnt,char) + (1-m)*adain(cnt,back) (run_ori.py:77-82, 228-232) against
+    the reference's outputs, plus the single-style form and bf16 storage."""
+    import json
+    from style_transfer_amd.features import adain, masked_adain_init
+    gold = np.load(os.path.join(GOLDEN, "adain.npz"))
+    cases = json.load(open(os.path.join(GOLDEN, "adain_cases.json")))
+    for c in cases:
+        cnt, char, back = (synth.normal(sd, tuple(c["shape"]), sigma=c["sigma"]) + np.float32(0.3 * j)
+                           for j, sd in enumerate(c["seeds"]))
+        mask = load_masks()[c["mask"]]
+        got = masked_adain_init(g(cnt), g(char), g(back), g(mask)).cpu().numpy()
+        assert rel_err(got, gold[f"blend/{c['id']}"]) < 1e-5, c
+        assert rel_err(got, orc.masked_adain_init(cnt, char, back, mask)) < 1e-5, c
+        assert rel_err(adain(g(cnt), g(char)).cpu().numpy(), gold[f"adain/{c['id']}"]) < 1e-5, c
+        b16 = masked_adain_init(g(cnt).bfloat16(), g(char).bfloat16(), g(back).bfloat16(), g(mask)).float().cpu().numpy()
+        r = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+        assert rel_err(b16, orc.masked_adain_init(r(cnt), r(char), r(back), mask)) < 2 ** -7, c

@@ -124,3 +124,17 @@ def test_schedules_match_reference():
     assert [int(t) for t in orc.make_ddim_timesteps_uniform(20)] == misc["ddim_timesteps_20"]
     assert [int(t) for t in orc.make_content_injection_schedule(ts)] == misc["content_injection_schedule_50"]
     assert [int(t) for t in orc.make_content_injection_schedule(ts, 0.25)] == misc["content_injection_schedule_50_a25"]
+
+
+def test_masked_adain_oracle_matches_reference_goldens():
+    """run_ori.py:77-82 (adain) and :228-232 (mask blend) against outputs of the reference's own
+    `adain` and the same torch calls."""
+    import json
+    gold = np.load(os.path.join(GOLDEN, "adain.npz"))
+    cases = json.load(open(os.path.join(GOLDEN, "adain_cases.json")))
+    for c in cases:
+        cnt, char, back = (synth.normal(sd, tuple(c["shape"]), sigma=c["sigma"]) + np.float32(0.3 * j)
+                           for j, sd in enumerate(c["seeds"]))
+        mask = load_masks()[c["mask"]]
+        assert rel_err(orc.adain(cnt, char), gold[f"adain/{c['id']}"]) < 2e-6, c
+        assert rel_err(orc.masked_adain_init(cnt, char, back, mask), gold[f"blend/{c['id']}"]) < 2e-6, c
