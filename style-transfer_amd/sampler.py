@@ -1,0 +1,59 @@
+"""DDIM sampling loop around the UNet, as the reference drives it for stylisation
+(ldm/models/diffusion/ddim.py:25-55 schedule, :155-240 loop, :286-322 update; run_ori.py:238-242):
+eta = 0, no classifier-free guidance (the conditioning is the unconditional embedding only), one
+UNet evaluation per step with that step's merged feature dict, and the steps whose index is
+>= start_step are skipped (with start_step = 49 of 50 that is the first, noisiest step)."""
+import numpy as np
+import torch
+
+
+def make_ddim_timesteps(num_ddim, num_ddpm=1000):
+    """uniform discretisation, +1 (ldm/modules/diffusionmodules/util.py:46-60): 1, 21, ..., 981."""
+    c = num_ddpm // num_ddim
+    return (np.arange(0, num_ddim) * c).astype(int) + 1
+
+
+class DDIMSampler:
+    def __init__(self, unet, num_ddpm=1000, linear_start=0.00085, linear_end=0.012):
+        self.unet = unet
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, num_ddpm, dtype=np.float64) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas)
+        self.num_ddpm = num_ddpm
+
+    def make_schedule(self, ddim_num_steps, ddim_eta=0.0):
+        ts = make_ddim_timesteps(ddim_num_steps, self.num_ddpm)
+        ac = self.alphas_cumprod
+        a = ac[ts]
+        a_prev = np.asarray([ac[0]] + ac[ts[:-1]].tolist())
+        self.ddim_timesteps = ts
+        self.ddim_alphas = a.astype(np.float32)
+        self.ddim_alphas_prev = a_prev.astype(np.float32)
+        self.ddim_sigmas = (ddim_eta * np.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))).astype(np.float32)
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1.0 - a).astype(np.float32)
+
+    @torch.no_grad()
+    def sample(self, x_T, unconditional_conditioning, injected_features=None, start_step=9999, callback=None,
+               generator=None):
+        """x_T (B,4,h,w) -> final latent.  `injected_features`: list indexed by loop position i
+        (i = 0 is the largest timestep), as feat_merge_2sty produces; `callback(i)` runs after step i
+        (the high-frequency patch reads the timestep it sets)."""
+        img = x_T
+        b = x_T.shape[0]
+        total = len(self.ddim_timesteps)
+        for i, step in enumerate(np.flip(self.ddim_timesteps)):
+            index = total - i - 1
+            if index >= start_step:
+                continue
+            ts = torch.full((b,), int(step), device=x_T.device, dtype=torch.long)
+            feats = injected_features[i] if injected_features else None
+            e_t = self.unet(img, ts, unconditional_conditioning, injected_features=feats)
+            a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
+            sigma_t = float(self.ddim_sigmas[index])
+            pred_x0 = (img - float(self.ddim_sqrt_one_minus_alphas[index]) * e_t) / a_t ** 0.5
+            dir_xt = (1.0 - a_prev - sigma_t ** 2) ** 0.5 * e_t
+            img = a_prev ** 0.5 * pred_x0 + dir_xt
+            if sigma_t > 0:
+                img = img + sigma_t * torch.randn(img.shape, device=img.device, generator=generator)
+            if callback is not None:
+                callback(i)
+        return img

@@ -84,3 +84,18 @@ def attention_inputs(seed, heads, n_tokens, head_dim, sigma_qk=1.0, sigma_v=1.0,
         sig = sigma_v if nm.startswith("v") else sigma_qk
         out[nm] = normal(seed * 16 + 1 + i, (bh, n_tokens, head_dim), sig)
     return out
+
+
+def param_init(name, shape):
+    """Deterministic parameter values from the parameter's NAME (so two implementations of one
+    network that agree on names get identical weights without a checkpoint): matrices and
+    convolutions ~ N(0, 1/fan_in), normalisation scales ~ 1 + 0.1 N(0,1), biases ~ 0.05 N(0,1)."""
+    import zlib
+    seed = zlib.crc32(name.encode()) & 0x7FFFFFFF
+    shape = tuple(shape)
+    if name.endswith("weight") and len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return normal(seed, shape, sigma=fan_in ** -0.5)
+    if name.endswith("weight"):
+        return (1.0 + normal(seed, shape, sigma=0.1)).astype(np.float32)
+    return normal(seed, shape, sigma=0.05)

@@ -295,8 +295,91 @@ def gen_adain():
     print("adain:", len(cases), "cases")
 
 
+UNET_CFG = dict(in_channels=4, out_channels=4, model_channels=160, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                channel_mult=[1, 2, 4, 4], num_heads=8, transformer_depth=1, context_dim=768)
+
+
+def unet_inputs(tag):
+    """Seeded latent, timestep and text context shared by the generator and the tests."""
+    base = {"cnt": 8100, "char": 8200, "back": 8300, "cur": 8400}[tag]
+    x = synth.normal(base, (1, 4, 16, 16))
+    ctx = synth.normal(8500, (1, 77, 768), sigma=0.5)
+    return x, ctx
+
+
+def gen_unet():
+    """Half-width SD-v1 topology (head dims 20/40/80, 12 output blocks) built from the REFERENCE's
+    UNetModel with name-seeded weights.  Three feature-extraction passes (gen_pkl=True, as
+    generate_pkl_only.py:90-134 does) give content / character / background q,k,v of output blocks
+    6-11; feat_merge_2sty (compiled from run_ori.py) merges them; one injected forward with a real
+    mask file gives the output this fixture pins, with checksums of the captured features."""
+    import ast
+    import types
+    stub = types.ModuleType("omegaconf")
+    stub.listconfig = types.ModuleType("omegaconf.listconfig")
+    stub.listconfig.ListConfig = list
+    sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = stub, stub.listconfig
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    torch.manual_seed(0)
+    model = UNetModel(image_size=32, use_spatial_transformer=True, use_checkpoint=False, legacy=False, **UNET_CFG).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(synth.param_init(name, p.shape)))
+    attns = [m for m in model.modules() if isinstance(m, ref_attn.CrossAttention)]
+    t = torch.tensor([481])
+    out = {}
+
+    def capture(tag):
+        for m in attns:
+            m.gen_pkl = True
+        x, ctx = unet_inputs(tag)
+        with torch.no_grad():
+            model(torch.from_numpy(x), t, torch.from_numpy(ctx))
+        feats = {"config": {"T": 1.5}, "z_enc": torch.from_numpy(x)}
+        for bi in range(6, 12):
+            a = model.output_blocks[bi][1].transformer_blocks[0].attn1
+            for nm in "qkv":
+                feats[f"output_block_{bi}_self_attn_{nm}"] = getattr(a, nm).clone()
+        for m in attns:
+            m.gen_pkl = False
+        return feats
+
+    feats = {tag: capture(tag) for tag in ("cnt", "char", "back")}
+    for tag, f in feats.items():
+        for k, v in f.items():
+            if torch.is_tensor(v) and k != "z_enc":
+                out[f"feat/{tag}/{k}"] = np.array([v.double().sum().item(), (v.double() ** 2).sum().item()])
+    src = open(os.path.join(REF, "run_ori.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "feat_merge_2sty"][0]
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "run_ori.py", "exec"), ns)
+    opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+    merged = ns["feat_merge_2sty"](opt, [feats["cnt"]] * 50, [feats["char"]] * 50, [feats["back"]] * 50, start_step=50)[0]
+    mask = np.load(os.path.join(MASK_DIR, MASK_NAMES[0] + ".npy"))
+    x, ctx = unet_inputs("cur")
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "img_mask.npy"), mask)
+        for m in attns:
+            m.cnt_name = os.path.join(td, "img.jpg")
+        with torch.no_grad():
+            out["injected"] = model(torch.from_numpy(x), t, torch.from_numpy(ctx), injected_features=merged).numpy()
+        for m in attns:
+            m.cnt_name = os.path.join(td, "nomask.jpg")
+        with torch.no_grad():
+            out["plain"] = model(torch.from_numpy(x), t, torch.from_numpy(ctx)).numpy()
+    np.savez_compressed(os.path.join(HERE, "unet.npz"), **out)
+    with open(os.path.join(HERE, "unet_case.json"), "w") as f:
+        json.dump({"cfg": UNET_CFG, "mask": MASK_NAMES[0], "t": 481, "gamma": 0.75, "T": 1.5,
+                   "n_params": sum(p.numel() for p in model.parameters()),
+                   "param_shapes": {n: list(p.shape) for n, p in model.named_parameters()}}, f)
+    print("unet: params", sum(p.numel() for p in model.parameters()), "out std", out["injected"].std(), out["plain"].std(),
+          "diff", np.abs(out["injected"] - out["plain"]).max())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain"]
+    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain", "unet"]
+    if "unet" in which:
+        gen_unet()
     if "adain" in which:
         gen_adain()
     if "feat_merge" in which:
