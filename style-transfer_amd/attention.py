@@ -116,8 +116,7 @@ class CrossAttention(nn.Module):
             self.k, self.v = feats[1], feats[2]
             q_cnt = feats[0]
             self._q, self._q_lazy = None, (lambda: q_cnt * gamma + self._split(xq) * (1. - 0.5))
-            out = ops.injected_attention(xq.contiguous(), *feats, m, gamma, T, self.scale, h,
-                                         q_self_coef=0.5, compute=compute)
+            out = self._injected(xq.contiguous(), feats, m, gamma, T, compute)
             return self.to_out(out)
 
         # single-block attention
@@ -141,9 +140,17 @@ class CrossAttention(nn.Module):
             logit_scale = T * self.scale                   # (:557-559)
         else:
             logit_scale = (T if (q_injected is not None or k_injected is not None) else 1.0) * self.scale
-        out = ops.plain_attention(q.contiguous(), self._as(k, q), self._as(v, q), logit_scale, h,
-                                  q_layout=q_layout, kv_layout=kv_layout, compute=compute)
+        out = self._plain(q.contiguous(), self._as(k, q), self._as(v, q), logit_scale, q_layout, kv_layout, compute)
         return self.to_out(out)
+
+    # The two kernel calls of the module.  (A measurement harness may subclass and override them to
+    # time another implementation inside the same network; the package itself has no other path.)
+    def _injected(self, xq, feats, m, gamma, T, compute):
+        return ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute)
+
+    def _plain(self, q, k, v, logit_scale, q_layout, kv_layout, compute):
+        return ops.plain_attention(q, k, v, logit_scale, self.heads, q_layout=q_layout, kv_layout=kv_layout,
+                                   compute=compute)
 
     @staticmethod
     def _as(t, like):
