@@ -57,3 +57,52 @@ class DDIMSampler:
             if callback is not None:
                 callback(i)
         return img
+
+    @torch.no_grad()
+    def encode_ddim(self, x0, unconditional_conditioning, num_steps=50, img_callback=None):
+        """DDIM inversion x0 -> x_T (ldm/models/diffusion/ddim.py:324-384): steps t = 1, 21, ..., 981,
+        each to the next one (the last to 999); `img_callback(pred_x0, x_next, t)` after every step."""
+        T = self.num_ddpm
+        c = T // num_steps
+        steps = list(range(1, T + c, c))
+        steps[-1] = T - 1
+        ac = self.alphas_cumprod
+        img, pred_x0 = x0, x0
+        for i, t in enumerate(range(1, T, c)):
+            ts = torch.full((x0.shape[0],), t, device=x0.device, dtype=torch.long)
+            e_t = self.unet(img, ts, unconditional_conditioning)
+            a_t, a_next = float(ac[t]), float(ac[steps[i + 1]])
+            pred_x0 = (img - (1.0 - a_t) ** 0.5 * e_t) / a_t ** 0.5
+            img = a_next ** 0.5 * pred_x0 + (1.0 - a_next) ** 0.5 * e_t
+            if img_callback is not None:
+                img_callback(pred_x0, img, t)
+        return img, pred_x0
+
+
+def extract_features(unet, x0, unconditional_conditioning, num_steps=50, blocks=range(6, 12), T=1.5):
+    """The producer of a `precomputed_feats_k` list (generate_pkl_only.py:90-142): DDIM inversion with the
+    attention modules in feature-extraction mode; after the step at timestep t the q, k, v of the
+    self-attention of output blocks 6-11 and the latent go to entry i = (981 - t) / 20, so entry 0
+    holds the fully inverted latent."""
+    sampler = DDIMSampler(unet)
+    sampler.make_schedule(num_steps, 0.0)
+    index_of = {int(t): i for i, t in enumerate(np.flip(sampler.ddim_timesteps))}
+    feats = [{"config": {"T": T}} for _ in range(num_steps)]
+    attns = unet.attention_modules()
+    for a in attns:
+        a.gen_pkl = True
+
+    def record(pred_x0, xt, t):
+        e = feats[index_of[int(t)]]
+        for b in blocks:
+            a = unet.output_blocks[b][1].transformer_blocks[0].attn1
+            for nm in "qkv":
+                e["output_block_%d_self_attn_%s" % (b, nm)] = getattr(a, nm).detach().clone()
+        e["z_enc"] = xt.detach().clone()
+
+    try:
+        sampler.encode_ddim(x0, unconditional_conditioning, num_steps, img_callback=record)
+    finally:
+        for a in attns:
+            a.gen_pkl = False
+    return feats
