@@ -55,7 +55,9 @@ def patch_decoder_resblocks_h_and_cnt_hf(unet, schedule, residuals_all, ratio=0.
             if not module.__class__.__name__.endswith("ResBlock"):
                 continue
             module.block_id = block_id
-            inner = module._forward
+            # patching again (next image, other residuals) replaces the previous patch, never nests
+            inner = getattr(module, "_unpatched_forward", None) or module._forward
+            module._unpatched_forward = inner
 
             def patched(self, x, emb, out_layers_injected=None, _inner=inner):
                 out = _inner(x, emb, out_layers_injected)
