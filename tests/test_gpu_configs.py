@@ -1,0 +1,76 @@
+"""The benchmark configurations at full size: batch 16 at the four UNet levels, and the 1024x1024
+levels (16384 and 4096 tokens, 128x128 feature maps).  Checked by sampled float64 oracle rows and by
+properties that need no full-size oracle."""
+import numpy as np
+import pytest
+import torch
+
+import sid_oracle as orc
+from helpers import rel_err
+from style_transfer_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+H = 8
+
+
+def dev_inputs(seed, B, N, d, sigma=1.0):
+    g = torch.Generator(device="cuda:0"); g.manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device="cuda:0", generator=g) * sigma
+    t = {"xq": rn(B, N, H * d)}
+    for k in ("q_cnt", "k1", "v1", "k2", "v2", "k_cnt", "v_cnt"):
+        t[k] = rn(B * H, N, d)
+    t["mask"] = torch.sign(rn(B, N)).contiguous()
+    return t
+
+
+def run(t, d, compute):
+    return ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"], t["mask"],
+                                  0.5, 1.5, d ** -0.5, H, compute=compute)
+
+
+def check_rows(t, out, b, rows, d, tol):
+    sl = slice(b * H, (b + 1) * H)
+    c = lambda x: x.cpu().numpy()
+    ref = orc.injected_attention_rows(rows, c(t["xq"][b]), c(t["q_cnt"][sl]), c(t["k1"][sl]), c(t["v1"][sl]), c(t["k2"][sl]),
+                                      c(t["v2"][sl]), c(t["k_cnt"][sl]), c(t["v_cnt"][sl]), c(t["mask"][b]), 0.5, 1.5, d ** -0.5)
+    assert rel_err(c(out[b])[rows], ref) < tol, b
+
+
+@pytest.mark.parametrize("N,d,sigma", [(4096, 40, 1.0), (1024, 80, 1.0), (256, 160, 1.0), (64, 160, 1.0), (4096, 40, 2.0)])
+def test_batch16_levels(N, d, sigma):
+    """Kernel microbenchmark configuration: 16 independent problems, each with its own mask; sigma 2 gives
+    feature-like logits (biases beyond +-100)."""
+    B = 16
+    t = dev_inputs(6000 + N, B, N, d, sigma)
+    out = run(t, d, "bf16")
+    assert torch.isfinite(out).all()
+    rows = (synth.hash_u64(6001, 12) % np.uint64(N)).astype(np.int64)
+    for b in (0, 7, 15):
+        check_rows(t, out, b, rows, d, 2e-2 if sigma == 1.0 else 4e-2)
+    ones = dict(t, v1=torch.ones_like(t["v1"]), v2=torch.ones_like(t["v2"]), v_cnt=torch.ones_like(t["v_cnt"]))
+    assert (run(ones, d, "bf16") - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("N,d", [(16384, 40), (4096, 80)])
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+def test_1024px_levels(N, d, compute):
+    """The 1024x1024 configuration: 16384-token top level and 4096-token second level."""
+    t = dev_inputs(6100 + N, 1, N, d)
+    out = run(t, d, compute)
+    assert torch.isfinite(out).all()
+    rows = (synth.hash_u64(6101, 16) % np.uint64(N)).astype(np.int64)
+    check_rows(t, out, 0, rows, d, 2e-2 if compute == "bf16" else 1e-3)
+
+
+def test_hf_filter_128px_maps():
+    """128x128 maps (the 1024x1024 configuration) at 320 channels: a sample of channels against the
+    oracle, idempotence over all of them."""
+    g = torch.Generator(device="cuda:0"); g.manual_seed(6200)
+    x = torch.randn(1, 320, 128, 128, device="cuda:0", generator=g)
+    s, h = torch.randn_like(x), torch.randn_like(x)
+    f = ops.hf_filter(x, 0.5)
+    ch = [0, 1, 77, 318, 319]
+    assert rel_err(f[:, ch].cpu().numpy(), orc.high_freq_filter(x[:, ch].cpu().numpy(), 0.5)) < 1e-5
+    assert rel_err(ops.hf_filter(f, 0.5).cpu().numpy(), f.cpu().numpy()) < 1e-5
+    fused = ops.hf_filter(x, 0.5, skip=s, h=h)
+    assert rel_err(fused.cpu().numpy(), (s + h + f).cpu().numpy()) < 1e-6
