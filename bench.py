@@ -50,6 +50,7 @@ def make_image_workload(dev, gen, dtype):
         return torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dtype)
 
     w = {"inj": [], "plain": [], "hf": []}
+    w["z"] = [rn(1, 4, 64, 64).float() for _ in range(3)]          # inverted latents of content / char / back
     for (N, d) in INJECTED:
         layer = {"N": N, "d": d, "xq": rn(1, N, HEADS * d), "feats": []}
         for _ in range(EVALS):
@@ -58,6 +59,7 @@ def make_image_workload(dev, gen, dtype):
         yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
         disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
         layer["mask"] = ops.mask_downsample(disc, side, side, 1.0)
+        w["mask512"] = disc
         w["inj"].append(layer)
     for (N, d, T) in PLAIN:
         w["plain"].append({"N": N, "d": d, "T": T, "q": rn(1, N, HEADS * d), "k": rn(1, N, HEADS * d),
@@ -68,8 +70,9 @@ def make_image_workload(dev, gen, dtype):
 
 
 def run_image(w, compute):
-    """The hot path of one image: 49 evaluations in UNet order."""
+    """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
     outs = None
+    ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
     for e in range(EVALS):
         for p in w["plain"][:7]:
             ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute)

@@ -37,6 +37,14 @@ for name, cs in acc.items():
 with open(os.path.join(dst, tag + "_attn4096_pmc.txt"), "w") as f:
     f.write("rocprofv3 --pmc <one pass per run> -- python3 tools/prof_attn.py 4096 40 1 3; mean per dispatch\n")
     f.write("FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them (uncorrected)\n\n" + "\n".join(lines) + "\n")
+if flash and "SQ_VALU_MFMA_BUSY_CYCLES" in flash and "GRBM_GUI_ACTIVE" in flash:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs on the chip -> SIMD-cycles of the dispatch
+    simd_cycles = flash["GRBM_GUI_ACTIVE"] / 8 * 1024
+    util = flash["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+    with open(os.path.join(dst, tag + "_attn4096_pmc.txt"), "a") as f:
+        f.write("\nflash kernel: matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) = %.3f\n" % util)
+        f.write("              VALU issue busy  = 4*SQ_ACTIVE_INST_VALU / SIMD-cycles = %.3f\n" % (4 * flash.get("SQ_ACTIVE_INST_VALU", 0) / simd_cycles))
+    print("mfma busy", util)
 if flash and "FETCH_SIZE" in flash:
     # gfx950: FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 bytes -> double it;
     # WRITE_SIZE is exact for 16-byte-per-lane stores.  Both are reported in KiB.
