@@ -314,6 +314,9 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
     fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = nblk; fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
+#ifdef SID_DIAG
+    fp.diag = (unsigned long long*)(getenv("SID_DIAG_PTR") ? strtoull(getenv("SID_DIAG_PTR"), nullptr, 0) : 0ull);
+#endif
     if (stg.flash) {
         const int rc = x3 ? launch_flash_x3(fp, g, stream) : launch_flash_bf16(fp, g, stream);
         if (rc != SID_OK) return rc;

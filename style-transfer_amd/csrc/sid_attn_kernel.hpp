@@ -56,6 +56,9 @@ struct FlashParams {
     int nblk;                    // 3: injected [char | back | content], 1: single block
     int direct;                  // single part: normalise and write `out` here, no merge kernel
     int out_bf16;
+#ifdef SID_DIAG
+    unsigned long long* diag;    // diagnostic build: clock stamps of workgroup (blockIdx.x), 8 per workgroup
+#endif
 };
 
 struct MergeParams {
@@ -298,6 +301,12 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
+#ifdef SID_DIAG
+    auto stamp = [&](int i) { if (tid == 0 && P.diag) P.diag[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+#else
+    auto stamp = [&](int) {};
+#endif
     const int NP = P.nblk * P.KS;
     const int BH = P.B * P.H;
 
@@ -421,8 +430,10 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
         wait_direct_loads();
         __syncthreads();
 
+        stamp(1);
         if (pass == 0) {
             run(F_{}, T_{}, Online{}, 0, min(1, nfull));              // first stage: exact running max
+            stamp(2);
             if (nfull > 1) {
                 if constexpr (SHIFT) {
                     // freeze the reference at a value two bf16 represent exactly and hand it to the MFMA
@@ -453,7 +464,9 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
         } else {
             run(F_{}, T_{}, Online{}, 0, nfull);
         }
+        stamp(3);
         run(T_{}, T_{}, Online{}, nfull, P.SPS);                      // stages with masked keys
+        stamp(4);
 
         bool over = false;
 #pragma unroll
@@ -531,6 +544,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             }
         }
     }
+    stamp(5);
 }
 
 template <int DKS, int DVB, bool X3, int NW, bool SHIFT>

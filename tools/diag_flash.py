@@ -1,0 +1,33 @@
+"""Diagnostic build only (exp/diag.so, -DSID_DIAG): per-workgroup clock stamps of the flash kernel.
+stamps: 0 entry, 1 first stage landed, 2 first stage done, 3 steady loop done, 4 tails done, 5 stored.
+memrealtime ticks at 100 MHz (10 ns)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+N, d, B = (int(sys.argv[i]) if len(sys.argv) > i else v for i, v in ((1, 1024), (2, 80), (3, 1)))
+dev = torch.device("cuda:0")
+diag = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
+os.environ["SID_DIAG_PTR"] = str(diag.data_ptr())
+os.environ["SID_LIB_OVERRIDE"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exp", "diag.so")
+from style_transfer_amd import ops
+H = 8
+g = torch.Generator(device=dev); g.manual_seed(0)
+rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+xq = rn(B, N, H * d); f = [rn(B * H, N, d) for _ in range(7)]; m = torch.sign(rn(B, N)).contiguous()
+for _ in range(5):
+    ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
+torch.cuda.synchronize()
+diag.zero_()
+ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
+torch.cuda.synchronize()
+t = diag.cpu().numpy().reshape(-1, 8)
+t = t[t[:, 0] > 0][:, :6].astype(np.float64)
+t0 = t[:, 0].min()
+print("workgroups", len(t), " kernel span %.2f us" % ((t[:, 5].max() - t0) / 100))
+names = ["entry->stage0 landed", "first stage", "steady loop", "tails", "store"]
+for i, nm in enumerate(names):
+    dlt = (t[:, i + 1] - t[:, i]) / 100
+    print("  %-22s mean %.2f us  min %.2f  max %.2f" % (nm, dlt.mean(), dlt.min(), dlt.max()))
+print("  wg lifetime            mean %.2f us  max %.2f" % (((t[:, 5] - t[:, 0]) / 100).mean(), ((t[:, 5] - t[:, 0]) / 100).max()))
+print("  entry time spread      first %.2f us last %.2f us" % (0.0, (t[:, 0].max() - t0) / 100))
+print("  end time spread        first %.2f us last %.2f us" % ((t[:, 5].min() - t0) / 100, (t[:, 5].max() - t0) / 100))
