@@ -75,15 +75,15 @@ def make_image_workload(dev, gen, dtype):
     return w
 
 
-def run_image(w, compute):
+def run_image(w, compute, flags=0):
     """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
     outs = None
     ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
     for e in range(EVALS):
         for p in w["plain"][:7]:
-            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute)
+            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
         for p in w["plain"][7:]:
-            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute)
+            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
         hf_on = e >= EVALS - HF_EVALS          # the 20 smallest timesteps come last
         for li, layer in enumerate(w["inj"]):
             if hf_on:
@@ -91,7 +91,7 @@ def run_image(w, compute):
                 ops.hf_filter(m["h_cnt"][e - (EVALS - HF_EVALS)], RATIO, skip=m["skip"], h=m["h"])
             f = layer["feats"][e]
             outs = ops.injected_attention(layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"],
-                                          GAMMA, TEMP, layer["d"] ** -0.5, HEADS, compute=compute)
+                                          GAMMA, TEMP, layer["d"] ** -0.5, HEADS, compute=compute, flags=flags)
     return outs
 
 
@@ -204,17 +204,18 @@ def main():
 
     # one lane per image in flight: a stream, and the image's launch sequence as a graph on it
     n_lanes = max(1, args.in_flight)
+    kflags = ops.FLAG_THROUGHPUT if n_lanes > 1 else 0      # images share the GPU: least-work decomposition
     lanes = []
     for _ in range(n_lanes):
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
-            run_image(w, args.compute)               # sizes this stream's workspace; first-use kernel attributes
+            run_image(w, args.compute, kflags)       # sizes this stream's workspace; first-use kernel attributes
         torch.cuda.synchronize()
         graph, gout = None, None
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=st):
-                gout = run_image(w, args.compute)
+                gout = run_image(w, args.compute, kflags)
         lanes.append((st, graph, gout))
     torch.cuda.synchronize()
 
@@ -225,7 +226,7 @@ def main():
                 graph.replay()
                 out = gout
             else:
-                out = run_image(w, args.compute)
+                out = run_image(w, args.compute, kflags)
             return out.reshape(-1)[:4 * 64 * 64].clone()    # stand-in for the (1,4,64,64) latent, 64 KiB
 
     for i in range(args.warmup):

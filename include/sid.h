@@ -46,6 +46,10 @@ extern "C" {
 
 /* flags (bit mask) */
 #define SID_FLAG_BLOCK_SKIP 1 /* reserved: skip key blocks whose weight underflows f32 */
+/* The call shares the GPU with other work of the caller (other streams): choose the decomposition
+ * with the least total work (no key-range splits, fewer partial results) instead of the one that
+ * fills an otherwise idle GPU. */
+#define SID_FLAG_THROUGHPUT 2
 /* Stage selection for measurement: an attention call is pack -> flash -> merge.  With none of
  * these bits set all three run.  A call that leaves out an earlier stage reuses what a previous
  * call with the same shape arguments left in the same workspace. */

@@ -53,6 +53,7 @@ class CrossAttention(nn.Module):
         self.target_t_list = None
         self.layer_id = None
         self.compute = None          # None: follow set_default_compute()
+        self.kernel_flags = 0        # e.g. ops.FLAG_THROUGHPUT when several images share the GPU
         self.mask_cache = default_cache
         self._q = None
         self._q_lazy = None
@@ -146,11 +147,12 @@ class CrossAttention(nn.Module):
     # The two kernel calls of the module.  (A measurement harness may subclass and override them to
     # time another implementation inside the same network; the package itself has no other path.)
     def _injected(self, xq, feats, m, gamma, T, compute):
-        return ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute)
+        return ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute,
+                                      flags=self.kernel_flags)
 
     def _plain(self, q, k, v, logit_scale, q_layout, kv_layout, compute):
         return ops.plain_attention(q, k, v, logit_scale, self.heads, q_layout=q_layout, kv_layout=kv_layout,
-                                   compute=compute)
+                                   compute=compute, flags=self.kernel_flags)
 
     @staticmethod
     def _as(t, like):

@@ -190,7 +190,7 @@ bool supported_dims(int d, int* DKS, int* DVB) {
 // Decomposition of one call: waves per workgroup and key splits -- sized so the grid covers the
 // 256 CUs with about two waves per SIMD while as many queries as possible share each K/V stage.
 // SID_TUNE_NW / SID_TUNE_KS override the choice (measurement only).
-int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, Geometry* g) {
+int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool throughput, Geometry* g) {
     if (!supported_dims(d, &g->DKS, &g->DVB))
         return sid::fail(SID_ENOSYS, "head_dim %d has no kernel instance (supported: 17-48, 49-64, 65-80, 81-96, 113-128, 145-160)", d);
     g->KVS = stage_tiles(g->DKS, g->DVB, x3);
@@ -212,7 +212,7 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, Geomet
     // amortise a workgroup's fixed cost and the partials it adds to the merge (measured: splitting
     // pays from about 16 stages per split)
     int ks = 1;
-    while (ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 16) ++ks;
+    while (!throughput && ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 16) ++ks;
     if (const char* e = getenv("SID_TUNE_KS")) ks = atoi(e);
     g->SPS = (stages + ks - 1) / ks;
     g->KS = (stages + g->SPS - 1) / g->SPS;               // drop splits that would hold no key
@@ -335,10 +335,14 @@ extern "C" size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, 
     Geometry g;
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
     const bool x3 = compute == SID_COMPUTE_F32X3;
-    if (make_geometry(B, H, N, N, d, kBlocks, x3, &g) != SID_OK) return 0;
-    Workspace w;
-    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w);
-    return w.bytes;
+    size_t bytes = 0;
+    for (int thr = 0; thr < 2; ++thr) {          // enough for either decomposition (SID_FLAG_THROUGHPUT)
+        if (make_geometry(B, H, N, N, d, kBlocks, x3, thr != 0, &g) != SID_OK) return 0;
+        Workspace w;
+        carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w);
+        bytes = std::max(bytes, w.bytes);
+    }
+    return bytes;
 }
 
 extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
@@ -358,7 +362,7 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
                   "gamma, q_self_coef, T and scale must be finite");
     const bool x3 = compute == SID_COMPUTE_F32X3;
     Geometry g;
-    rc = make_geometry(B, H, N, N, d, kBlocks, x3, &g);
+    rc = make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
     if (rc != SID_OK) return rc;
     Workspace w;
     carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w);
@@ -417,10 +421,14 @@ extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, i
     if (check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
     if (use_small_path(Nk, d)) return 256;       // the single-launch path keeps nothing in the workspace
     const bool x3 = compute == SID_COMPUTE_F32X3;
-    if (make_geometry(B, H, Nq, Nk, d, 1, x3, &g) != SID_OK) return 0;
-    Workspace w;
-    carve(g, 1, 1, x3, (long long)B * H * Nq, d, nullptr, &w);
-    return w.bytes;
+    size_t bytes = 0;
+    for (int thr = 0; thr < 2; ++thr) {
+        if (make_geometry(B, H, Nq, Nk, d, 1, x3, thr != 0, &g) != SID_OK) return 0;
+        Workspace w;
+        carve(g, 1, 1, x3, (long long)B * H * Nq, d, nullptr, &w);
+        bytes = std::max(bytes, w.bytes);
+    }
+    return bytes;
 }
 
 extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq,
@@ -446,7 +454,7 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
         return launch_small_attn(q, k, v, out, B, H, Nq, Nk, d, logit_scale * LOG2E, qs, ks, dtype == SID_DTYPE_BF16, x3, stream);
     }
     Geometry g;
-    rc = make_geometry(B, H, Nq, Nk, d, 1, x3, &g);
+    rc = make_geometry(B, H, Nq, Nk, d, 1, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
     if (rc != SID_OK) return rc;
     Workspace w;
     carve(g, 1, 1, x3, (long long)B * H * Nq, d, workspace, &w);

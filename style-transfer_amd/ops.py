@@ -86,7 +86,10 @@ def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, ga
     return out
 
 
-def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="bf16", out=None):
+FLAG_THROUGHPUT = 2      # SID_FLAG_THROUGHPUT: the caller keeps the GPU busy with other streams
+
+
+def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="bf16", out=None, flags=0):
     """softmax((q k^T) * logit_scale) v.  Layout 'bnhd': (B,N,H*d); 'bhnd': (B*H,N,d).
     Returns (B, Nq, H*d)."""
     L = _lib.load()
@@ -117,7 +120,7 @@ def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnh
     ws = _workspace(dev, nbytes)
     with torch.cuda.device(dev):
         _lib.check(L.sid_plain_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk, d,
-                                        float(logit_scale), lay[q_layout], lay[kv_layout], dt, cc, 0,
+                                        float(logit_scale), lay[q_layout], lay[kv_layout], dt, cc, int(flags),
                                         ws.data_ptr(), ws.numel(), _stream(dev)))
     return out
 

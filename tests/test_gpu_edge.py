@@ -265,3 +265,19 @@ def test_hf_filter_both_kernels(path, dtype, monkeypatch):
         assert rel_err(got, want) < tol, (n, c, ratio)
         bare = ops.hf_filter(x.cuda(), ratio).float().cpu().numpy()
         assert rel_err(bare, orc.high_freq_filter(x.float().numpy(), ratio)) < tol, (n, c, ratio)
+
+
+def test_throughput_flag_changes_the_decomposition_not_the_rows():
+    """SID_FLAG_THROUGHPUT (no key-range splits) against the default decomposition."""
+    H, N, d = 8, 4096, 40
+    t = synth.attention_inputs(5300, H, N, d, 1.0, 1.0, 1)
+    tt = {k: g(v) for k, v in t.items()}
+    m = g(np.sign(synth.normal(5301, (N,))).astype(np.float32))
+    call = lambda flags: ops.injected_attention(tt["xq"], tt["q_cnt"], tt["k1"], tt["v1"], tt["k2"], tt["v2"], tt["k_cnt"],
+                                                tt["v_cnt"], m, 0.75, 1.5, d ** -0.5, H, compute="fp32", flags=flags)
+    a, b = call(0).cpu().numpy(), call(ops.FLAG_THROUGHPUT).cpu().numpy()
+    assert rel_err(a, b) < 1e-4          # two summation orders of the same f32-grade products
+    x = tt["xq"]
+    p0 = ops.plain_attention(x, x, x, d ** -0.5, H, compute="fp32").cpu().numpy()
+    p1 = ops.plain_attention(x, x, x, d ** -0.5, H, compute="fp32", flags=ops.FLAG_THROUGHPUT).cpu().numpy()
+    assert rel_err(p0, p1) < 1e-4
