@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,23 +185,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the path has no CPU fallback)")
     sid_lib.load()
+    if os.environ.get("SID_BENCH_ONE_DEVICE") == "1":      # rehearsal of the N-rank flow on a one-GPU box (with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     dtype = torch.float32 if args.io == "f32" else torch.bfloat16
     w = make_image_workload(dev, gen, dtype)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # one lane per image in flight: a stream, and the image's launch sequence as a graph on it
     n_lanes = max(1, args.in_flight)
@@ -214,10 +206,25 @@ def main():
         graph, gout = None, None
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=st):
+            with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
                 gout = run_image(w, args.compute, kflags)
         lanes.append((st, graph, gout))
     torch.cuda.synchronize()
+
+    # the process group comes after graph capture, so no communicator thread touches the device meanwhile
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     def one_image(i):
         st, graph, gout = lanes[i % n_lanes]
@@ -236,13 +243,15 @@ def main():
     latents = [one_image(i) for i in range(args.steps)]
     torch.cuda.synchronize()
     mine = torch.stack(latents).float()
+    if dist is not None and args.backend == "gloo":
+        mine = mine.cpu()
     gathered = sharding.gather_latents(mine, dist, dst=0)  # the one collective of the job (RCCL gather)
     if rank == 0:
         assert gathered.shape[0] == world and gathered.shape[1] == args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
