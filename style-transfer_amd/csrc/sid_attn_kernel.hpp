@@ -551,13 +551,11 @@ template <int DKS, int DVB, bool X3, int NW, bool SHIFT>
 int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     constexpr int KVS = stage_tiles(DKS, DVB, X3);
     constexpr int QT = query_tiles(DKS, DVB, X3);
-    auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT>;
-    if (g.lds > 48 * 1024) {
-        static bool done = false;   // one device per process: the attribute is set once per instance
-        if (!done) {
-            SID_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
-            done = true;
-        }
+    constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT>;
+    constexpr size_t lds_need = 2 * KVS * tile_bytes(DKS, DVB, X3);
+    if (lds_need > 48 * 1024) {
+        const int rc = sid::allow_dynamic_lds<kern>(lds_need);
+        if (rc != SID_OK) return rc;
     }
     const long long grid = (long long)g.nQG * fp.B * fp.H * fp.nblk * fp.KS;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), g.lds, stream, fp);

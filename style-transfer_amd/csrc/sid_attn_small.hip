@@ -498,12 +498,9 @@ int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream
     const size_t p_off = (images + 255) / 256 * 256;
     const size_t st_off = p_off + (size_t)kSmallMaxTiles * 2 * 1024;
     const size_t lds = st_off + 2 * kSmallMaxTiles * 32 * sizeof(float);
-    auto kern = small_attn_lds_kernel<DKS, MODE>;
-    static bool done = false;     // one device per process: the attribute is set once per instance
-    if (!done) {
-        SID_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        done = true;
-    }
+    constexpr auto kern = small_attn_lds_kernel<DKS, MODE>;
+    const int rc = sid::allow_dynamic_lds<kern>(160 * 1024);
+    if (rc != SID_OK) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(BH * p.NQT)), dim3(waves * 64), lds, stream, p, vst, (int)p_off, (int)st_off);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;

@@ -430,13 +430,10 @@ template <int H, int W, bool BF16>
 int launch_hf(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int radius,
               hipStream_t stream) {
     const size_t lds = (size_t)(64 + H * (W + 1)) * sizeof(float2);
-    auto kern = hf_kernel<H, W, BF16>;
+    constexpr auto kern = hf_kernel<H, W, BF16>;
     if (lds > 48 * 1024) {
-        static bool done = false;
-        if (!done) {
-            SID_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done = true;
-        }
+        const int rc = sid::allow_dynamic_lds<kern>(lds);
+        if (rc != SID_OK) return rc;
     }
     const int pairs = (C + 1) / 2;
     hipLaunchKernelGGL(kern, dim3(B * pairs), dim3(256), lds, stream, hcnt, skip, hres, out, C, pairs,
