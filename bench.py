@@ -50,35 +50,38 @@ MFMA_PEAK = 2.5e15                # dense bf16 MFMA, FLOP/s (MI355X spec)
 HBM_PEAK = 8.0e12
 
 
-def make_image_workload(dev, gen, dtype):
-    """All tensors one image's hot path reads, resident on `dev`."""
+def make_image_workload(dev, gen, dtype, batch=1):
+    """All tensors the hot path of `batch` images (processed together, one problem per image) reads,
+    resident on `dev`."""
+    B = batch
     def rn(*shape):
         return torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dtype)
 
-    w = {"inj": [], "plain": [], "hf": []}
-    w["z"] = [rn(1, 4, 64, 64).float() for _ in range(3)]          # inverted latents of content / char / back
+    w = {"inj": [], "plain": [], "hf": [], "batch": B}
+    w["z"] = [[rn(1, 4, 64, 64).float() for _ in range(3)] for _ in range(B)]   # inverted latents: content / char / back
     for (N, d) in INJECTED:
-        layer = {"N": N, "d": d, "xq": rn(1, N, HEADS * d), "feats": []}
+        layer = {"N": N, "d": d, "xq": rn(B, N, HEADS * d), "feats": []}
         for _ in range(EVALS):
-            layer["feats"].append([rn(HEADS, N, d) for _ in range(7)])   # q_cnt k1 v1 k2 v2 k_cnt v_cnt
+            layer["feats"].append([rn(B * HEADS, N, d) for _ in range(7)])   # q_cnt k1 v1 k2 v2 k_cnt v_cnt
         side = int(N ** 0.5)
         yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
         disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
-        layer["mask"] = ops.mask_downsample(disc, side, side, 1.0)
+        layer["mask"] = ops.mask_downsample(disc, side, side, 1.0).repeat(B).reshape(B, -1).contiguous()
         w["mask512"] = disc
         w["inj"].append(layer)
     for (N, d, T) in PLAIN:
-        w["plain"].append({"N": N, "d": d, "T": T, "q": rn(1, N, HEADS * d), "k": rn(1, N, HEADS * d),
-                           "v": rn(1, N, HEADS * d)})
+        w["plain"].append({"N": N, "d": d, "T": T, "q": rn(B, N, HEADS * d), "k": rn(B, N, HEADS * d),
+                           "v": rn(B, N, HEADS * d)})
     for (C, S) in HF_MAPS:
-        w["hf"].append({"h_cnt": [rn(1, C, S, S) for _ in range(HF_EVALS)], "skip": rn(1, C, S, S), "h": rn(1, C, S, S)})
+        w["hf"].append({"h_cnt": [rn(B, C, S, S) for _ in range(HF_EVALS)], "skip": rn(B, C, S, S), "h": rn(B, C, S, S)})
     return w
 
 
 def run_image(w, compute, flags=0):
     """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
     outs = None
-    ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
+    for z in w["z"]:
+        ops.masked_adain(z[0], z[1], z[2], w["mask512"])
     for e in range(EVALS):
         for p in w["plain"][:7]:
             ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
@@ -198,16 +201,21 @@ def main():
     n_lanes = max(1, args.in_flight)
     kflags = ops.FLAG_THROUGHPUT if n_lanes > 1 else 0      # images share the GPU: least-work decomposition
     lanes = []
+    graph_error = None
     for _ in range(n_lanes):
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
             run_image(w, args.compute, kflags)       # sizes this stream's workspace; first-use kernel attributes
         torch.cuda.synchronize()
         graph, gout = None, None
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
-                gout = run_image(w, args.compute, kflags)
+        if not args.no_graph and graph_error is None:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+                    gout = run_image(w, args.compute, kflags)
+            except Exception as e:                   # same kernels, launched one by one instead
+                graph, gout, graph_error = None, None, "%s: %s" % (type(e).__name__, e)
+                torch.cuda.synchronize()
         lanes.append((st, graph, gout))
     torch.cuda.synchronize()
 
@@ -276,7 +284,8 @@ def main():
                                    "49 UNet evaluations: 6 injected + 10 self attention calls each, fused HF filter "
                                    "on 6 ResBlocks for 20 evaluations; hot path only (UNet convs/VAE not run)",
                        "feature_storage": args.io, "images_per_rank": args.steps, "images_in_flight": n_lanes,
-                       "launch": "kernel by kernel" if args.no_graph else "one HIP graph per image",
+                       "launch": ("kernel by kernel" if args.no_graph else "one HIP graph per image") if graph_error is None
+                       else "kernel by kernel (graph capture failed: %s)" % graph_error[:120],
                        "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,4,true> injected attention N=4096 d=40 H=8 B=1",
                          "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
