@@ -98,14 +98,16 @@ def run_image(w, compute, flags=0):
     return outs
 
 
-def flash_kernel_time(w, compute, reps=50):
+def flash_kernel_time(w, compute, reps=300):
     """Average duration of the dominant kernel (the flash stage at N=4096, d=40), HIP events on
-    the launch stream around `reps` back-to-back launches."""
+    the launch stream around `reps` back-to-back launches.  The same number of untimed launches runs
+    first: after an idle gap the chip takes tens of milliseconds to return to its working clock
+    (measured: 103 us per launch right after 2 s of idle, 84 us sustained)."""
     layer = w["inj"][-1]
     f = layer["feats"][0]
     args = (layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"], GAMMA, TEMP, layer["d"] ** -0.5, HEADS)
     ops.injected_attention(*args, compute=compute)                      # full call fills the workspace
-    for _ in range(5):
+    for _ in range(reps):
         ops.injected_attention(*args, compute=compute, flags=0x20)      # flash stage only
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
