@@ -62,6 +62,15 @@ def test_argument_checks_reject_without_a_gpu():
     assert rc == -22 and b"NULL" in L.sid_last_error()
     rc = L.sid_plain_attn_fwd(None, None, None, None, 1, 8, 0, 64, 40, 0.1, 0, 0, 0, 0, 0, None, 0, None)
     assert rc == -22
+    rc = L.sid_masked_adain(None, None, None, None, 512, 512, None, 1, 4, 64, 64, 0, None)
+    assert rc == -22 and b"NULL" in L.sid_last_error()
+    one = 0x1000                                          # non-NULL placeholders: rejected before any dereference
+    rc = L.sid_masked_adain(one, one, one, None, 512, 512, one, 1, 4, 64, 64, 0, None)
+    assert rc == -22 and b"mask and sty_back" in L.sid_last_error()
+    rc = L.sid_masked_adain(one, one, None, None, 0, 0, one, 1, 4, 1, 1, 0, None)
+    assert rc == -22 and b"at least two elements" in L.sid_last_error()
+    assert L.sid_plain_attn_workspace_bytes(1, 8, 4096, 77, 40, 0) == 256        # single-launch path: no scratch
+    assert L.sid_plain_attn_workspace_bytes(1, 8, 4096, 4096, 40, 0) > 256
     rc = L.sid_hf_filter(None, None, None, None, 1, 4, 64, 64, 0.5, 0, None)
     assert rc == -22
     buf = ctypes.create_string_buffer(16)
