@@ -293,7 +293,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK, "traffic": measured_traffic(), "kernel_ms": t_flash * 1e3,
                          "algorithmic_flop": flops},
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # N = 1 only
         }
         print(json.dumps(line))
     if dist is not None:
