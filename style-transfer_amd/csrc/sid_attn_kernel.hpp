@@ -93,6 +93,13 @@ constexpr int stage_tiles(int DKS, int DVB, bool x3) { return 2 * 2 * tile_bytes
 // query tiles per wave: two where the accumulators of both fit the 256-register budget
 constexpr int query_tiles(int DKS, int DVB, bool x3) { return (!x3 && DKS <= 3 && DVB <= 2) ? 2 : 1; }
 
+// Registers the software-pipelined loop keeps live (accumulators, two sets of logits and packed
+// probabilities, Q, K and V fragments); the kernel uses it where they leave room in the 256-register
+// budget of two waves per SIMD, and the plain stage loop elsewhere.
+constexpr int pipeline_registers(int DKS, int DVB, int QT) {
+    return 16 * DVB * QT + 32 + 16 + 4 * DKS * QT + 4 * DKS + (QT == 1 ? 2 : 1) * 8 * DVB;
+}
+
 int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_merge(const MergeParams& mp, hipStream_t stream);
@@ -273,6 +280,176 @@ __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, 
     }
 }
 
+// ---- Software-pipelined steady state ------------------------------------------------------------
+// On gfx950 a 32x32x16 MFMA occupies the matrix pipe for 32 cycles but the wave's issue port for only
+// about 8; v_exp_f32 takes about 7 issue cycles, the other vector ops about 4.  A wave issues in order,
+// so matrix and vector work only overlap when they alternate in the instruction stream.  The pipelined
+// stage therefore runs three units (a unit = one query tile x one key tile) at once:
+//
+//      slot u:   vector ops of softmax(u)   interleaved with   MFMAs of  P.V(u-1)  and  K.Q'(u+1)
+//
+// one MFMA followed by an equal share of the unit's vector ops, with a scheduling fence after each
+// group so the compiler keeps the interleave.  The pipeline runs across stage boundaries: the logits
+// of the next stage's first unit are computed in the last slot of a stage (after the barrier that
+// publishes that stage), and the P.V of a stage's last unit runs in the first slot of the next.
+enum { kOpExp, kOpCvt, kOpMax, kOpMin, kOpUpdMax, kOpUpdMin };
+struct SoftmaxOps { int n; int kind[64]; int arg[64]; };
+// The vector ops of one unit in issue order: per pair of logits two exponentials, a step of the max
+// (and min) tree, and the bf16 packing of the previous pair.
+constexpr SoftmaxOps softmax_ops(bool track_min) {
+    SoftmaxOps t{};
+    int n = 0;
+    for (int g = 0; g < 8; ++g) {
+        t.kind[n] = kOpExp; t.arg[n++] = 2 * g;
+        t.kind[n] = kOpExp; t.arg[n++] = 2 * g + 1;
+        t.kind[n] = kOpMax; t.arg[n++] = g;
+        if (track_min) { t.kind[n] = kOpMin; t.arg[n++] = g; }
+        if (g > 0) { t.kind[n] = kOpCvt; t.arg[n++] = g - 1; }
+    }
+    t.kind[n] = kOpCvt; t.arg[n++] = 7;
+    t.kind[n] = kOpUpdMax; t.arg[n++] = 0;
+    if (track_min) { t.kind[n] = kOpUpdMin; t.arg[n++] = 0; }
+    t.n = n;
+    return t;
+}
+
+template <int DKS, int DVB, int KVS, int QT, bool TRACK_MIN, int MODE>
+struct StagePipe {
+    static_assert(KVS % 2 == 0, "fragment registers alternate by key tile parity");
+    static_assert(MODE == kFixed || MODE == kShifted, "the reference is frozen in the pipelined loop");
+    static constexpr int U = KVS * QT;            // units per stage
+    static constexpr int NM = DKS + 2 * DVB;      // MFMAs per slot
+    static constexpr int KU = KVS * DKS * 64;     // u32x4 offset of the V image in a stage
+    static constexpr SoftmaxOps T = softmax_ops(TRACK_MIN);
+    using QF = Frags<DKS, false>;
+
+    f32x16 S[2];                       // logits: unit parity
+    bf16x8 Pk[2][2];                   // packed probabilities: unit parity, k-step
+    Frags<DKS, false> kf;              // K fragments of the tile the next logits are taken against
+    static constexpr int NVS = QT == 1 ? 2 : 1;
+    Frags<2 * DVB, false> vf[NVS];     // V^T fragments of the tile(s) of the running P.V
+    float e[16];
+    float tmax, tmin;
+
+    template <int I>
+    __device__ __forceinline__ void op(const f32x16& Sx, bf16x8 (&Px)[2], RowState& r) {
+        constexpr int kind = T.kind[I], a = T.arg[I];
+        if constexpr (kind == kOpExp) {
+            e[a] = __builtin_amdgcn_exp2f(MODE == kShifted ? Sx[a] : Sx[a] - r.m2);
+        } else if constexpr (kind == kOpCvt) {
+            Px[a / 4][2 * (a % 4)] = (__bf16)e[2 * a];
+            Px[a / 4][2 * (a % 4) + 1] = (__bf16)e[2 * a + 1];
+        } else if constexpr (kind == kOpMax) {
+            if constexpr (a == 0) tmax = fmaxf(fmaxf(Sx[0], Sx[1]), Sx[2]);
+            else if constexpr (a < 7) tmax = fmaxf(fmaxf(tmax, Sx[2 * a + 1]), Sx[2 * a + 2]);
+            else tmax = fmaxf(tmax, Sx[15]);
+        } else if constexpr (kind == kOpMin) {
+            if constexpr (a == 0) tmin = fminf(fminf(Sx[0], Sx[1]), Sx[2]);
+            else if constexpr (a < 7) tmin = fminf(fminf(tmin, Sx[2 * a + 1]), Sx[2 * a + 2]);
+            else tmin = fminf(tmin, Sx[15]);
+        } else if constexpr (kind == kOpUpdMax) {
+            r.smax = fmaxf(r.smax, MODE == kShifted ? tmax + r.m2 : tmax);     // unshifted coordinates
+        } else {
+            r.smin = fminf(r.smin, MODE == kShifted ? tmin + r.m2 : tmin);
+        }
+    }
+
+    __device__ __forceinline__ void load_k(const u32x4* L, int tile, int lane) { kf.load(L + (tile * DKS) * 64 + lane, 0); }
+    // one k-step half (DVB fragments) of a V tile
+    template <int SET>
+    __device__ __forceinline__ void load_v(const u32x4* L, int tile, int half, int lane) {
+#pragma unroll
+        for (int b = 0; b < DVB; ++b)
+            vf[SET].hi[half * DVB + b] = as_bf16x8(L[KU + (tile * 2 * DVB + half * DVB + b) * 64 + lane]);
+    }
+
+    // Before the first slot: the logits of the stage's first unit; a zero P.V stands in for unit -1.
+    __device__ __forceinline__ void begin(const u32x4* L, int lane, const QF (&qf)[QT]) {
+        load_k(L, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 2 * DVB; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) vf[NVS - 1].hi[i][c] = (__bf16)0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { Pk[1][0][c] = (__bf16)0.f; Pk[1][1][c] = (__bf16)0.f; }
+        S[0] = qk_tile<DKS, false>(kf, qf[0]);
+        if constexpr (QT == 1) {
+            load_k(L, 1, lane);
+            load_v<0>(L, 0, 0, lane);
+            load_v<0>(L, 0, 1, lane);
+        }
+    }
+
+    // Slot u of the stage at L; Lnext is the following stage (read only in the last slot).
+    //
+    // Fragment registers are reloaded as soon as the last MFMA that reads them has been issued.  The
+    // MFMAs of a slot run  P.V k-step 0 | K.Q' chain | P.V k-step 1, so
+    //   * the k-step-0 half of a V set is free after the first DVB MFMAs and the k-step-1 half after
+    //     the last, and the halves of a later tile are read then.  With QT > 1 there is one set and
+    //     the reload happens in the slot of a tile's FIRST unit; with QT == 1 every slot ends a tile, so
+    //     there are two sets (tile parity) and slot u fetches tile u+1 into the set tile u-1 leaves.
+    //     Either way all V reads of a stage precede the barrier, after which its buffer is overwritten
+    //     (with QT == 1 the last slot reads the first V tile of the NEXT stage);
+    //   * K is free after the chain; the next tile's K is read then, one slot ahead of its use, except
+    //     the next stage's first tile, which is only visible in the last slot and is read at its start
+    //     (the chain comes DVB MFMAs later).
+    template <int u>
+    __device__ __forceinline__ void slot(const u32x4* L, const u32x4* Lnext, int lane, const QF (&qf)[QT],
+                                         f32x16 (&O)[QT][DVB], RowState (&rs)[QT]) {
+        constexpr int t = u % QT;
+        constexpr int tn = (u + 1) % QT;                       // query tile of the unit whose logits are produced
+        constexpr int tp = (u + U - 1) % QT;                   // ... of the unit whose P.V is produced
+        constexpr int sc = u & 1, sn = (u + 1) & 1;
+        constexpr int vs = QT == 1 ? (u + 1) & 1 : 0;          // V set read by this slot's P.V
+        auto reload_v = [&](int half) {
+            if constexpr (QT > 1) {
+                if constexpr (u % QT == 0) load_v<0>(L, u / QT, half, lane);
+            } else if constexpr (u + 1 < U) {
+                load_v<vs>(L, u + 1, half, lane);
+            } else {
+                load_v<vs>(Lnext, 0, half, lane);
+            }
+        };
+        if constexpr (u == U - 1) load_k(Lnext, 0, lane);
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m < DVB) {
+                O[tp][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[vs].hi[m], Pk[sn][0], O[tp][m], 0, 0, 0);
+                if constexpr (m == DVB - 1) reload_v(0);
+            } else if constexpr (m < DVB + DKS) {
+                constexpr int s = m - DVB;
+                if constexpr (s == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                    S[sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[0], qf[tn].hi[0], z, 0, 0, 0);
+                } else {
+                    S[sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[s], qf[tn].hi[s], S[sn], 0, 0, 0);
+                }
+                if constexpr (s == DKS - 1 && (u + 2) % QT == 0) {
+                    if constexpr (u + 2 < U) load_k(L, (u + 2) / QT, lane);
+                    else if constexpr (u == U - 1) load_k(Lnext, (u + 2 - U) / QT, lane);   // QT == 1 only
+                }
+            } else {
+                constexpr int b = m - DVB - DKS;
+                O[tp][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[vs].hi[DVB + b], Pk[sn][1], O[tp][b], 0, 0, 0);
+                if constexpr (b == DVB - 1) reload_v(1);
+            }
+            static_for<m * T.n / NM, (m + 1) * T.n / NM>([&](auto ic) { op<decltype(ic)::value>(S[sc], Pk[sc], rs[t]); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    // After the last slot: the P.V of the last unit.
+    __device__ __forceinline__ void finish(f32x16 (&O)[QT][DVB]) {
+#pragma unroll
+        for (int b = 0; b < DVB; ++b) {
+            O[QT - 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NVS - 1].hi[b], Pk[1][0], O[QT - 1][b], 0, 0, 0);
+            O[QT - 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NVS - 1].hi[DVB + b], Pk[1][1], O[QT - 1][b], 0, 0, 0);
+        }
+    }
+};
+
 // Direct global->LDS load of one 1 KiB unit: lane l's 16 bytes at src + l land at dst + l.
 // Written as asm on purpose: the compiler then neither counts the load nor orders LDS reads behind
 // it (with the builtin it waits vmcnt(0) before the next ds_read, which serialises the prefetch
@@ -302,7 +479,13 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
 #ifdef SID_DIAG
-    auto stamp = [&](int i) { if (tid == 0 && P.diag) P.diag[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime(); };
+    // stamps 0..5: constant 100 MHz counter; 6, 7: the shader cycle counter at stamps 2 and 3 (the steady loop)
+    auto stamp = [&](int i) {
+        if (tid == 0 && P.diag) {
+            P.diag[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+            if (i == 2 || i == 3) P.diag[(size_t)blockIdx.x * 8 + 4 + i] = __builtin_readcyclecounter();
+        }
+    };
     stamp(0);
 #else
     auto stamp = [&](int) {};
@@ -352,24 +535,21 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     const unsigned lane_bytes = lane * 16;
 
     // Stage copy: every 1 KiB unit is one wave-wide direct load; the NW waves take the units of each
-    // image round-robin.
+    // image round-robin.  Branch-free (the pipelined loop must stay one basic block): where the unit
+    // count is not a multiple of NW, the surplus waves copy the image's last unit once more.
     auto issue_stage = [&](int st, int buf) {
-        const u32x4* sk = gk + (size_t)st * KU + wave * 64;
-        const u32x4* sv = gv + (size_t)st * VU + wave * 64;
-        const unsigned dk = lds0 + (unsigned)(buf * SU + wave * 64) * 16;
+        const unsigned dk = lds0 + (unsigned)(buf * SU) * 16;
         static_for<0, (KUn + NW - 1) / NW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (KUn % NW == 0 || wave + i * NW < KUn) {
-                glds16(sk + i * NW * 64, lane_bytes, dk + i * NW * 1024);
-                if (X3) glds16(gkl + (size_t)st * KU + (wave + i * NW) * 64, lane_bytes, dk + (PU + i * NW * 64) * 16);
-            }
+            const int un = (KUn % NW == 0 || (i + 1) * NW <= KUn) ? wave + i * NW : min(wave + i * NW, KUn - 1);
+            glds16(gk + (size_t)st * KU + un * 64, lane_bytes, dk + un * 1024);
+            if (X3) glds16(gkl + (size_t)st * KU + un * 64, lane_bytes, dk + (PU + un * 64) * 16);
         });
         static_for<0, (VUn + NW - 1) / NW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if (VUn % NW == 0 || wave + i * NW < VUn) {
-                glds16(sv + i * NW * 64, lane_bytes, dk + (KU + i * NW * 64) * 16);
-                if (X3) glds16(gvl + (size_t)st * VU + (wave + i * NW) * 64, lane_bytes, dk + (PU + KU + i * NW * 64) * 16);
-            }
+            const int un = (VUn % NW == 0 || (i + 1) * NW <= VUn) ? wave + i * NW : min(wave + i * NW, VUn - 1);
+            glds16(gv + (size_t)st * VU + un * 64, lane_bytes, dk + (KU + un * 64) * 16);
+            if (X3) glds16(gvl + (size_t)st * VU + un * 64, lane_bytes, dk + (PU + KU + un * 64) * 16);
         });
     };
 
@@ -380,7 +560,8 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
 
     // Stages [it0, it1) of this part with ONE variant of the stage body per loop, so that every loop
     // is straight-line code.
-    auto run = [&](auto tail_c, auto min_c, auto mode_c, int it0, int it1) {
+    // `issued`: the copy of stage it0 + 1 is already in flight (the pipelined loop runs one ahead).
+    auto run = [&](auto tail_c, auto min_c, auto mode_c, int it0, int it1, bool issued = false) {
         constexpr bool TAIL = decltype(tail_c)::value, TMIN = decltype(min_c)::value;
         constexpr int MODE = decltype(mode_c)::value;
         for (int it = it0; it < it1; ++it) {
@@ -389,11 +570,38 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             // iteration.  At this point nothing is in flight (the previous iteration drained it), so
             // this wait is free; it only resets the compiler's bookkeeping.
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            if (it + 1 < P.SPS) issue_stage(st0 + it + 1, (it + 1) & 1);
+            if (it + 1 < P.SPS && !(issued && it == it0)) issue_stage(st0 + it + 1, (it + 1) & 1);
             process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE>(lds + (it & 1) * SU, lane, hh,
                                                                    (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
             wait_direct_loads();
             __syncthreads();          // stage it+1 has landed in every wave's view; stage it is free
+        }
+    };
+    // The same stages through the software pipeline (StagePipe).  On entry stage it0 is visible and
+    // nothing is in flight, as for `run`; on exit stage it1 is visible and the copy of stage it1 + 1 is
+    // in flight.  The barrier sits before the last slot of a stage: by then every wave has read all
+    // fragments of the stage into registers, so the buffer can take the stage after next, and the
+    // next stage must be visible because the last slot starts on it.
+    constexpr bool kPipelined = !X3 && KVS % 2 == 0 && pipeline_registers(DKS, DVB, QT) <= 190;
+    auto run_pipe = [&](auto min_c, auto mode_c, int it0, int it1) {
+        if constexpr (kPipelined) {
+            constexpr int U = KVS * QT;
+            StagePipe<DKS, DVB, KVS, QT, decltype(min_c)::value, decltype(mode_c)::value> pipe;
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see `run`
+            if (it0 + 1 < P.SPS) issue_stage(st0 + it0 + 1, (it0 + 1) & 1);
+            pipe.begin(lds + (it0 & 1) * SU, lane, qf);
+            for (int it = it0; it < it1; ++it) {
+                const u32x4* L = lds + (it & 1) * SU;
+                const u32x4* Ln = lds + ((it + 1) & 1) * SU;
+                static_for<0, U - 1>([&](auto uc) { pipe.template slot<decltype(uc)::value>(L, Ln, lane, qf, O, rs); });
+                wait_direct_loads();
+                __syncthreads();
+                // unconditional (no branch in the loop body): past the end the last stage is copied again
+                // into the buffer that has just become free, which nothing reads
+                issue_stage(st0 + min(it + 2, P.SPS - 1), it & 1);
+                pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
+            }
+            pipe.finish(O);
         }
     };
     using T_ = std::true_type;
@@ -431,6 +639,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
         __syncthreads();
 
         stamp(1);
+        bool ahead = false;       // the pipelined loop has already issued the copy of stage nfull + 1
         if (pass == 0) {
             run(F_{}, T_{}, Online{}, 0, min(1, nfull));              // first stage: exact running max
             stamp(2);
@@ -452,20 +661,29 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
                         bf16x2 pr = {h1, h2};
                         set_shift(t, __builtin_bit_cast(unsigned, pr));
                     }
-                    if (need_min) run(F_{}, T_{}, Shifted{}, 1, nfull);
-                    else run(F_{}, F_{}, Shifted{}, 1, nfull);
+                    if constexpr (kPipelined) {
+                        if (need_min) run_pipe(T_{}, Shifted{}, 1, nfull);
+                        else run_pipe(F_{}, Shifted{}, 1, nfull);
+                    } else {
+                        if (need_min) run(F_{}, T_{}, Shifted{}, 1, nfull);
+                        else run(F_{}, F_{}, Shifted{}, 1, nfull);
+                    }
 #pragma unroll
                     for (int t = 0; t < QT; ++t) set_shift(t, 0u);
+                } else if constexpr (kPipelined) {
+                    if (need_min) run_pipe(T_{}, Fixed{}, 1, nfull);
+                    else run_pipe(F_{}, Fixed{}, 1, nfull);
                 } else {
                     if (need_min) run(F_{}, T_{}, Fixed{}, 1, nfull);
                     else run(F_{}, F_{}, Fixed{}, 1, nfull);
                 }
+                ahead = kPipelined;
             }
         } else {
             run(F_{}, T_{}, Online{}, 0, nfull);
         }
         stamp(3);
-        run(T_{}, T_{}, Online{}, nfull, P.SPS);                      // stages with masked keys
+        run(T_{}, T_{}, Online{}, nfull, P.SPS, ahead);               // stages with masked keys
         stamp(4);
 
         bool over = false;

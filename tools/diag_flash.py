@@ -21,7 +21,9 @@ diag.zero_()
 ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
 torch.cuda.synchronize()
 t = diag.cpu().numpy().reshape(-1, 8)
-t = t[t[:, 0] > 0][:, :6].astype(np.float64)
+t = t[t[:, 0] > 0].astype(np.float64)
+cyc = t[:, 7] - t[:, 6]
+t = t[:, :6]
 t0 = t[:, 0].min()
 print("workgroups", len(t), " kernel span %.2f us" % ((t[:, 5].max() - t0) / 100))
 names = ["entry->stage0 landed", "first stage", "steady loop", "tails", "store"]
@@ -31,3 +33,6 @@ for i, nm in enumerate(names):
 print("  wg lifetime            mean %.2f us  max %.2f" % (((t[:, 5] - t[:, 0]) / 100).mean(), ((t[:, 5] - t[:, 0]) / 100).max()))
 print("  entry time spread      first %.2f us last %.2f us" % (0.0, (t[:, 0].max() - t0) / 100))
 print("  end time spread        first %.2f us last %.2f us" % ((t[:, 5].min() - t0) / 100, (t[:, 5].max() - t0) / 100))
+steady = (t[:, 3] - t[:, 2]) * 10e-9
+ok = steady > 0
+print("  shader clock in the steady loop: %.2f GHz (mean over workgroups), cycles per workgroup %.0f" % ((cyc[ok] / steady[ok]).mean() / 1e9, cyc[ok].mean()))
