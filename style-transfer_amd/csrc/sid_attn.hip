@@ -208,16 +208,40 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     if (const char* e = getenv("SID_TUNE_NW")) nw = atoi(e);
     g->NW = nw;
     g->nQG = (qwaves + nw - 1) / nw;
-    // key splits: until there are >= 2 workgroups per CU, while every split keeps enough stages to
-    // amortise a workgroup's fixed cost and the partials it adds to the merge (measured: splitting
-    // pays from about 16 stages per split)
-    int ks = 1;
-    while (!throughput && ks < 8 && BH * nblk * ks * g->nQG < 512 && stages / (ks + 1) >= 16) ++ks;
-    if (const char* e = getenv("SID_TUNE_KS")) ks = atoi(e);
-    g->SPS = (stages + ks - 1) / ks;
-    g->KS = (stages + g->SPS - 1) / g->SPS;               // drop splits that would hold no key
-    g->NKT = g->KS * g->SPS * g->KVS;                     // every split owns exactly SPS stages; surplus tiles are zero
-    g->lds = 2 * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
+    // Runs per (head, query group).  The nblk * stages key stages of a head are cut into W equal runs
+    // (a run may span a block boundary).  Cost model in units of one stage: a workgroup costs its
+    // G stages plus a fixed ~4 (prologue, store); workgroups execute in rounds of `slots` (two waves
+    // per SIMD), and every partial slot per block adds a little to the merge.  Runs shorter than 16
+    // stages do not pay (measured), so they are not considered unless the whole sequence is shorter.
+    // Concurrent callers (throughput) take one run per block: the fewest partials, no rounding loss
+    // to recover because other kernels fill the machine.
+    const int T = nblk * stages;
+    auto slots_per_block = [&](int G_) {
+        int most = 1;
+        for (int b = 0; b < nblk; ++b) most = std::max(most, ((b + 1) * stages - 1) / G_ - (b * stages) / G_ + 1);
+        return most;
+    };
+    int W = nblk;
+    if (!throughput) {
+        const long long pairs = BH * g->nQG, slots = 512LL * 4 / nw;
+        double best = 1e30;
+        for (int w = 1; w <= 8 * nblk && w <= T; ++w) {
+            const int G_ = (T + w - 1) / w;
+            if (G_ < std::min(16, stages)) break;
+            const long long rounds = (pairs * w + slots - 1) / slots;
+            const double cost = (double)rounds * (G_ + 4) + 2.0 * slots_per_block(G_);
+            if (cost < best - 1e-9) { best = cost; W = w; }
+        }
+    }
+    if (const char* e = getenv("SID_TUNE_KS")) W = nblk * atoi(e);       // the same number of runs per block
+    if (const char* e = getenv("SID_TUNE_W")) W = atoi(e);
+    W = std::max(1, std::min(W, T));
+    g->SPB = stages;
+    g->G = (T + W - 1) / W;
+    g->W = (T + g->G - 1) / g->G;                         // drop runs that would hold no stage
+    g->KS = slots_per_block(g->G);
+    g->NKT = stages * g->KVS;                             // whole stages; surplus tiles are zero
+    g->lds = (size_t)ring_stages(g->DKS, g->DVB, x3) * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
     g->q_units = (size_t)BH * g->NQT * g->DKS * 64;
     g->k_units = (size_t)BH * g->NKT * g->DKS * 64;
     g->v_units = (size_t)BH * g->NKT * 2 * g->DVB * 64;
@@ -313,7 +337,7 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
                     hipStream_t stream) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
-    fp.KS = g.KS; fp.SPS = g.SPS; fp.nblk = nblk; fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
+    fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.G = g.G; fp.nblk = nblk; fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
 #ifdef SID_DIAG
     fp.diag = (unsigned long long*)(getenv("SID_DIAG_PTR") ? strtoull(getenv("SID_DIAG_PTR"), nullptr, 0) : 0ull);
 #endif
@@ -590,7 +614,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
             const float w = st[1] > 0.f ? __builtin_amdgcn_exp2f(st[0] + bias_of(p) - M2) : 0.f;
             den += w * (st[1] > 0.f ? st[1] : 0.f);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += w * o_[p][e];
+            for (int e = 0; e < VEC; ++e) acc[e] += st[1] > 0.f ? w * o_[p][e] : 0.f;    // an unused slot holds no data
         }
     } else {
         for (int p = 0; p < nparts; ++p) {

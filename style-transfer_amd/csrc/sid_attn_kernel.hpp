@@ -13,11 +13,13 @@
 //   already the B operand of  O^T += V^T P^T  (dv on rows, queries on lanes): P never leaves
 //   registers, and every per-query quantity (running max, scale, sum) is a per-lane scalar.
 //
-// Decomposition: a workgroup is NW waves that share the K/V stages of ONE part (a key block, or a
-// key range of one) of one head; a wave owns QT tiles of 32 queries, so each K/V fragment read from
-// LDS feeds QT MFMAs.  Every (part, head, query) writes an un-normalised partial (O, l, m) plus the
-// raw row max/min of q.k; merge_kernel turns the statistics into the mask bias and combines the
-// parts.  A single-part call writes the normalised rows directly.
+// Decomposition: a workgroup is NW waves that share K/V stages of one head; a wave owns QT tiles of 32
+// queries, so each K/V fragment read from LDS feeds QT MFMAs.  The key stages of all blocks of a head
+// form one sequence that is cut into W equal runs, one workgroup per (run, query group): a run that
+// crosses a block boundary is processed as consecutive segments.  Every (segment, head, query) writes
+// an un-normalised partial (O, l, m) plus the raw row max/min of q.k; merge_kernel turns the statistics
+// into the mask bias and combines the partials.  A call with a single segment writes the normalised
+// rows directly.
 #pragma once
 #include "sid_common.h"
 
@@ -45,14 +47,15 @@ struct FlashParams {
     float c2[kBlocks];           // logit scale of each block, log2 domain: x = (q.k) * c2; already applied to
                                  // the packed query images, never zero (the host clamps |c2| >= 2^-40)
     int shift_cols;              // head_dim % 16 == 8: key images carry ones in columns d, d+1
-    float* opart;                // [part][BH][Nq][d] un-normalised partial outputs
-    float* stats;                // [part][BH][Nq][4] = (m2, l, smax, smin)
+    float* opart;                // [slot][BH][Nq][d] un-normalised partial outputs, slot = blk * KS + segment
+    float* stats;                // [slot][BH][Nq][4] = (m2, l, smax, smin); l == 0 marks an unused slot
     void* out;                   // (B, Nq, H*d), written here only when direct != 0
     int B, H, Nq, Nk, d;
     int NQT, NKT;                // 32-row tiles in the packed query / key images
-    int nQG;                     // workgroups per (head, part)
-    int KS;                      // key splits per block; parts = nblk * KS
-    int SPS;                     // stages per split
+    int nQG;                     // query groups (workgroups per (head, run))
+    int KS;                      // partial slots per block (the most segments any block is cut into)
+    int SPB;                     // stages per block
+    int W, G;                    // runs per (head, query group); stages per run: W * G >= nblk * SPB
     int nblk;                    // 3: injected [char | back | content], 1: single block
     int direct;                  // single part: normalise and write `out` here, no merge kernel
     int out_bf16;
@@ -78,8 +81,9 @@ struct Geometry {
     int KVS;           // 32-key tiles per LDS stage
     int QT;            // 32-query tiles per wave
     int NW;            // waves per workgroup
-    int KS;            // key splits per block
-    int SPS;           // stages per split
+    int KS;            // partial slots per block
+    int SPB;           // stages per block
+    int W, G;          // runs per (head, query group) over the nblk * SPB stages, stages per run
     int NQT, NKT;      // tiles in the packed images
     int nQG;
     size_t lds;
@@ -99,6 +103,16 @@ constexpr int query_tiles(int DKS, int DVB, bool x3) { return (!x3 && DKS <= 3 &
 constexpr int pipeline_registers(int DKS, int DVB, int QT) {
     return 16 * DVB * QT + 32 + 16 + 4 * DKS * QT + 4 * DKS + (QT == 1 ? 2 : 1) * 8 * DVB;
 }
+
+// the software-pipelined loop is used by this instance
+constexpr bool pipelined(int DKS, int DVB, bool x3) {
+    return !x3 && stage_tiles(DKS, DVB, x3) % 2 == 0 && pipeline_registers(DKS, DVB, query_tiles(DKS, DVB, x3)) <= 190;
+}
+// LDS stage buffers (a ring: stage s lives in buffer s % ring_stages, and a stage is requested
+// ring_stages - 1 stages of compute before it is used).  Two: deeper rings were measured (three and
+// four buffers at head_dim 40) and gain nothing -- the loop waits on LDS fragment reads and on issue
+// slots, not on the copy -- while every extra buffer takes LDS from whatever shares the CU.
+constexpr int ring_stages(int DKS, int DVB, bool x3) { return 2; }
 
 int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
@@ -133,7 +147,7 @@ struct RowState {
 
 // How a tile's exponentials are referenced:
 //   kOnline : exact online softmax; m2 follows the running row max and O is rescaled every tile
-//             (first stage, tail stages, and the fallback pass)
+//             (tail stages and the fallback pass)
 //   kFixed  : m2 frozen, p = exp2(x - m2)
 //   kShifted: m2 frozen AND already subtracted by the MFMA itself: two spare (zero-padding) columns of
 //             the query fragments hold -m2 as a bf16 pair and the key image holds ones there, so the
@@ -474,6 +488,8 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     constexpr int PU = KU + VU;               // one precision part
     constexpr int SU = PU * (X3 ? 2 : 1);     // one stage: [K hi | V hi | K lo | V lo]
     constexpr int KUn = KU / 64, VUn = VU / 64;
+    constexpr int NB = ring_stages(DKS, DVB, X3);                                    // stage buffers; stage s lives in s % NB
+    constexpr int NL = ((KUn + NW - 1) / NW + (VUn + NW - 1) / NW) * (X3 ? 2 : 1);  // direct loads per wave and stage
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -490,12 +506,11 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
 #else
     auto stamp = [&](int) {};
 #endif
-    const int NP = P.nblk * P.KS;
     const int BH = P.B * P.H;
 
-    // workgroup -> ((head, part), query group); workgroups that stream the same K/V image get ids
+    // workgroup -> ((head, run), query group); workgroups that stream the same K/V images get ids
     // equal mod 8 when the group count allows, i.e. they share an XCD and its L2 (speed only)
-    const int groups = BH * NP;
+    const int groups = BH * P.W;
     int grp, qg;
     {
         const int id = blockIdx.x;
@@ -508,28 +523,21 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             qg = id % P.nQG;
         }
     }
-    const int part = grp % NP, bh = grp / NP;
-    const int blk = part / P.KS, ks = part - blk * P.KS;
+    // The key stages of the nblk blocks form one sequence of nblk * SPB stages; run w of W covers
+    // stages [w * G, (w + 1) * G) of it.  Where a run crosses a block boundary the workgroup finishes
+    // one segment (its own partial output and statistics) and starts the next.
+    const int run_w = grp % P.W, bh = grp / P.W;
+    const int g0 = run_w * P.G, g1 = min(g0 + P.G, P.nblk * P.SPB);
 
     // this wave's query tiles; surplus tiles redo the last one and store nothing
     const int qt0 = (qg * NW + wave) * QT;
     Frags<DKS, X3> qf[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int qt = min(qt0 + t, P.NQT - 1);
-        qf[t].load(P.q[blk] + ((size_t)(bh * P.NQT + qt) * DKS) * 64 + lane,
-                   X3 ? (int)(P.q_lo[blk] - P.q[blk]) : 0);
-    }
 
-    const float c2 = P.c2[blk];
-    const bool need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || c2 < 0.f;
-    const int st0 = ks * P.SPS;
-
-    // wave-uniform image pointers of this (block, head); the lane offset is added by the load
-    const u32x4* gk = P.k[blk] + (size_t)bh * P.NKT * DKS * 64;
-    const u32x4* gv = P.v[blk] + (size_t)bh * P.NKT * 2 * DVB * 64;
-    const u32x4* gkl = X3 ? P.k_lo[blk] + (size_t)bh * P.NKT * DKS * 64 : nullptr;
-    const u32x4* gvl = X3 ? P.v_lo[blk] + (size_t)bh * P.NKT * 2 * DVB * 64 : nullptr;
+    // per segment: block, first stage and stage count within the block, partial slot, scale, images
+    int blk = 0, st0 = 0, slen = 0, part = 0;
+    float c2 = 1.f;
+    bool need_min = false;
+    const u32x4 *gk = nullptr, *gv = nullptr, *gkl = nullptr, *gvl = nullptr;   // wave-uniform; lane offset added by the load
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(
         (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds));
     const unsigned lane_bytes = lane * 16;
@@ -538,7 +546,7 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     // image round-robin.  Branch-free (the pipelined loop must stay one basic block): where the unit
     // count is not a multiple of NW, the surplus waves copy the image's last unit once more.
     auto issue_stage = [&](int st, int buf) {
-        const unsigned dk = lds0 + (unsigned)(buf * SU) * 16;
+        const unsigned dk = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * SU) * 16);   // uniform by construction
         static_for<0, (KUn + NW - 1) / NW>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int un = (KUn % NW == 0 || (i + 1) * NW <= KUn) ? wave + i * NW : min(wave + i * NW, KUn - 1);
@@ -556,52 +564,61 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
     f32x16 O[QT][DVB];
     RowState rs[QT];
     __shared__ int redo;
-    if (tid == 0) redo = 0;
 
     // Stages [it0, it1) of this part with ONE variant of the stage body per loop, so that every loop
     // is straight-line code.
-    // `issued`: the copy of stage it0 + 1 is already in flight (the pipelined loop runs one ahead).
-    auto run = [&](auto tail_c, auto min_c, auto mode_c, int it0, int it1, bool issued = false) {
+    // Stages of the segment whose copy has been issued so far (the prologue starts NB at once and the
+    // pipelined loop runs NB - 1 stages in front, so the plain loop below must not issue those again).
+    int nissued = 0;
+    auto run = [&](auto tail_c, auto min_c, auto mode_c, int it0, int it1) {
         constexpr bool TAIL = decltype(tail_c)::value, TMIN = decltype(min_c)::value;
         constexpr int MODE = decltype(mode_c)::value;
         for (int it = it0; it < it1; ++it) {
             // Nothing the compiler counts may be outstanding once the direct loads are in flight: its
             // counted vmcnt waits do not know about them and would wait for the oldest one in every
-            // iteration.  At this point nothing is in flight (the previous iteration drained it), so
-            // this wait is free; it only resets the compiler's bookkeeping.
+            // iteration.  At this point nothing is in flight as a rule (the previous iteration
+            // drained it), so this wait is free; it only resets the compiler's bookkeeping.
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            if (it + 1 < P.SPS && !(issued && it == it0)) issue_stage(st0 + it + 1, (it + 1) & 1);
-            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE>(lds + (it & 1) * SU, lane, hh,
+            if (it + 1 < slen && nissued <= it + 1) {
+                issue_stage(st0 + it + 1, (it + 1) % NB);
+                nissued = it + 2;
+            }
+            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE>(lds + (it % NB) * SU, lane, hh,
                                                                    (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
             wait_direct_loads();
             __syncthreads();          // stage it+1 has landed in every wave's view; stage it is free
         }
     };
-    // The same stages through the software pipeline (StagePipe).  On entry stage it0 is visible and
-    // nothing is in flight, as for `run`; on exit stage it1 is visible and the copy of stage it1 + 1 is
-    // in flight.  The barrier sits before the last slot of a stage: by then every wave has read all
-    // fragments of the stage into registers, so the buffer can take the stage after next, and the
-    // next stage must be visible because the last slot starts on it.
-    constexpr bool kPipelined = !X3 && KVS % 2 == 0 && pipeline_registers(DKS, DVB, QT) <= 190;
+    // The same stages through the software pipeline (StagePipe), with the NB stage buffers as a ring.
+    // On entry stage it0 is visible; stages up to it0 + NB - 1 are issued here unless they already are.
+    // In iteration `it` the barrier sits before the last slot: by then every wave has read all fragments
+    // of stage `it` into registers, so its buffer can take stage it + NB, and stage it + 1 must be
+    // visible because the last slot starts on it.  Loads complete in order and every iteration issues
+    // the same number, so "all but the youngest NB - 2 stages have landed" is a constant vmcnt.
+    constexpr bool kPipelined = pipelined(DKS, DVB, X3);
     auto run_pipe = [&](auto min_c, auto mode_c, int it0, int it1) {
         if constexpr (kPipelined) {
             constexpr int U = KVS * QT;
             StagePipe<DKS, DVB, KVS, QT, decltype(min_c)::value, decltype(mode_c)::value> pipe;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see `run`
-            if (it0 + 1 < P.SPS) issue_stage(st0 + it0 + 1, (it0 + 1) & 1);
-            pipe.begin(lds + (it0 & 1) * SU, lane, qf);
+            for (int k = 1; k < NB; ++k)
+                if (nissued <= it0 + k && it0 + k < slen) { issue_stage(st0 + it0 + k, (it0 + k) % NB); nissued = it0 + k + 1; }
+            wait_direct_loads();                  // (nothing to wait for after the prologue)
+            __syncthreads();
+            pipe.begin(lds + (it0 % NB) * SU, lane, qf);
             for (int it = it0; it < it1; ++it) {
-                const u32x4* L = lds + (it & 1) * SU;
-                const u32x4* Ln = lds + ((it + 1) & 1) * SU;
+                const u32x4* L = lds + (it % NB) * SU;
+                const u32x4* Ln = lds + ((it + 1) % NB) * SU;
                 static_for<0, U - 1>([&](auto uc) { pipe.template slot<decltype(uc)::value>(L, Ln, lane, qf, O, rs); });
-                wait_direct_loads();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NL) : "memory");
                 __syncthreads();
                 // unconditional (no branch in the loop body): past the end the last stage is copied again
                 // into the buffer that has just become free, which nothing reads
-                issue_stage(st0 + min(it + 2, P.SPS - 1), it & 1);
+                issue_stage(st0 + min(it + NB, slen - 1), it % NB);
                 pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
             }
             pipe.finish(O);
+            nissued = max(nissued, min(slen, it1 + NB));
         }
     };
     using T_ = std::true_type;
@@ -618,13 +635,32 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
         qf[t].hi[DKS - 1] = as_bf16x8(w);
     };
 
-    // stages of this part that hold only valid keys (every part runs SPS stages; the rest are tails)
-    const int nfull = max(0, min(P.SPS, P.Nk / (KVS * 32) - st0));
+    for (blk = g0 / P.SPB; blk * P.SPB < g1; ++blk) {
+    st0 = max(g0 - blk * P.SPB, 0);
+    slen = min(g1 - blk * P.SPB, P.SPB) - st0;
+    const int first_run = (blk * P.SPB) / P.G;               // the run that holds the block's first stage
+    part = blk * P.KS + (run_w - first_run);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qt = min(qt0 + t, P.NQT - 1);
+        qf[t].load(P.q[blk] + ((size_t)(bh * P.NQT + qt) * DKS) * 64 + lane,
+                   X3 ? (int)(P.q_lo[blk] - P.q[blk]) : 0);
+    }
+    c2 = P.c2[blk];
+    need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || c2 < 0.f;
+    gk = P.k[blk] + (size_t)bh * P.NKT * DKS * 64;
+    gv = P.v[blk] + (size_t)bh * P.NKT * 2 * DVB * 64;
+    gkl = X3 ? P.k_lo[blk] + (size_t)bh * P.NKT * DKS * 64 : nullptr;
+    gvl = X3 ? P.v_lo[blk] + (size_t)bh * P.NKT * 2 * DVB * 64 : nullptr;
+    if (tid == 0) redo = 0;           // published by the barrier of the prologue below
 
-    // Pass 0 holds the softmax reference fixed after the first stage (no rescaling in the loop).  If
-    // afterwards some row of the workgroup turns out to have exceeded its reference by more than
-    // 2^kOverflowThr (logits that grow that much along the keys), pass 1 redoes the workgroup with the
-    // exact online rescale in every tile.
+    // stages of this segment that hold only valid keys (the rest are tails)
+    const int nfull = max(0, min(slen, P.Nk / (KVS * 32) - st0));
+
+    // Pass 0 takes every row's largest logit over the FIRST stage as the softmax reference and holds it
+    // fixed (no rescaling in the loop).  If afterwards some row of the workgroup turns out to have
+    // exceeded its reference by more than 2^kOverflowThr (logits that grow that much along the keys),
+    // pass 1 redoes the workgroup with the exact online rescale in every tile.
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -634,57 +670,67 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
                 for (int i = 0; i < 16; ++i) O[t][b][i] = 0.f;
             rs[t].m2 = -SID_INF; rs[t].smax = -SID_INF; rs[t].smin = SID_INF;
         }
-        issue_stage(st0, 0);
+        // the first NB stages start together: their latencies (and that of the query fragments above)
+        // overlap
+        nissued = min(NB, slen);
+        for (int k = 0; k < nissued; ++k) issue_stage(st0 + k, k);
         wait_direct_loads();
         __syncthreads();
 
         stamp(1);
-        bool ahead = false;       // the pipelined loop has already issued the copy of stage nfull + 1
         if (pass == 0) {
-            run(F_{}, T_{}, Online{}, 0, min(1, nfull));              // first stage: exact running max
-            stamp(2);
-            if (nfull > 1) {
+            if (nfull > 0) {
+                // the reference: every row's largest logit over the first stage (logits only, no P.V)
+                {
+                    float m[QT];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) m[t] = -SID_INF;
+#pragma unroll
+                    for (int j = 0; j < KVS; ++j) {
+                        Frags<DKS, X3> kf;
+                        kf.load(lds + (j * DKS) * 64 + lane, PU);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) m[t] = fmaxf(m[t], max16(qk_tile<DKS, X3>(kf, qf[t])));
+                    }
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) rs[t].m2 = fmaxf(m[t], __shfl_xor(m[t], 32));
+                }
+                stamp(2);
                 if constexpr (SHIFT) {
                     // freeze the reference at a value two bf16 represent exactly and hand it to the MFMA
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
                         const __bf16 h1 = (__bf16)(-rs[t].m2);
                         const __bf16 h2 = (__bf16)(-rs[t].m2 - (float)h1);
-                        const float m2r = -((float)h1 + (float)h2);
-                        const float adj = __builtin_amdgcn_exp2f(rs[t].m2 - m2r);
-#pragma unroll
-                        for (int b = 0; b < DVB; ++b)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) O[t][b][i] *= adj;
-                        rs[t].m2 = m2r;
+                        rs[t].m2 = -((float)h1 + (float)h2);
                         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                         bf16x2 pr = {h1, h2};
                         set_shift(t, __builtin_bit_cast(unsigned, pr));
                     }
                     if constexpr (kPipelined) {
-                        if (need_min) run_pipe(T_{}, Shifted{}, 1, nfull);
-                        else run_pipe(F_{}, Shifted{}, 1, nfull);
+                        if (need_min) run_pipe(T_{}, Shifted{}, 0, nfull);
+                        else run_pipe(F_{}, Shifted{}, 0, nfull);
                     } else {
-                        if (need_min) run(F_{}, T_{}, Shifted{}, 1, nfull);
-                        else run(F_{}, F_{}, Shifted{}, 1, nfull);
+                        if (need_min) run(F_{}, T_{}, Shifted{}, 0, nfull);
+                        else run(F_{}, F_{}, Shifted{}, 0, nfull);
                     }
 #pragma unroll
                     for (int t = 0; t < QT; ++t) set_shift(t, 0u);
                 } else if constexpr (kPipelined) {
-                    if (need_min) run_pipe(T_{}, Fixed{}, 1, nfull);
-                    else run_pipe(F_{}, Fixed{}, 1, nfull);
+                    if (need_min) run_pipe(T_{}, Fixed{}, 0, nfull);
+                    else run_pipe(F_{}, Fixed{}, 0, nfull);
                 } else {
-                    if (need_min) run(F_{}, T_{}, Fixed{}, 1, nfull);
-                    else run(F_{}, F_{}, Fixed{}, 1, nfull);
+                    if (need_min) run(F_{}, T_{}, Fixed{}, 0, nfull);
+                    else run(F_{}, F_{}, Fixed{}, 0, nfull);
                 }
-                ahead = kPipelined;
             }
         } else {
             run(F_{}, T_{}, Online{}, 0, nfull);
         }
         stamp(3);
-        run(T_{}, T_{}, Online{}, nfull, P.SPS, ahead);               // stages with masked keys
+        run(T_{}, T_{}, Online{}, nfull, slen);                      // stages with masked keys
         stamp(4);
+        wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
 
         bool over = false;
 #pragma unroll
@@ -759,9 +805,19 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             if (hh == 0) {
                 f32x4 st = {rs[t].m2, lsum, smax, smin};
                 *(f32x4*)(P.stats + row * 4) = st;
+                // a block cut into fewer segments than there are partial slots per block: the first
+                // segment marks the unused slots empty (sum 0; the merge skips them)
+                if (run_w == first_run) {
+                    const int last_run = ((blk + 1) * P.SPB - 1) / P.G;
+                    for (int pp = last_run - first_run + 1; pp < P.KS; ++pp) {
+                        f32x4 none = {-SID_INF, 0.f, -SID_INF, SID_INF};
+                        *(f32x4*)(P.stats + ((((size_t)blk * P.KS + pp) * BH + bh) * P.Nq + q) * 4) = none;
+                    }
+                }
             }
         }
     }
+    }   // segments
     stamp(5);
 }
 
@@ -770,12 +826,12 @@ int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stre
     constexpr int KVS = stage_tiles(DKS, DVB, X3);
     constexpr int QT = query_tiles(DKS, DVB, X3);
     constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT>;
-    constexpr size_t lds_need = 2 * KVS * tile_bytes(DKS, DVB, X3);
+    constexpr size_t lds_need = (size_t)ring_stages(DKS, DVB, X3) * KVS * tile_bytes(DKS, DVB, X3);
     if (lds_need > 48 * 1024) {
         const int rc = sid::allow_dynamic_lds<kern>(lds_need);
         if (rc != SID_OK) return rc;
     }
-    const long long grid = (long long)g.nQG * fp.B * fp.H * fp.nblk * fp.KS;
+    const long long grid = (long long)g.nQG * fp.B * fp.H * fp.W;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), g.lds, stream, fp);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;

@@ -122,6 +122,24 @@ def test_forced_key_splits_and_workgroup_widths(ks, nw, monkeypatch):
 
 
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("W,N,d", [(1, 1000, 40), (2, 1000, 40), (4, 1000, 40), (5, 1000, 40), (7, 2048, 40), (2, 700, 80),
+                                   (5, 1024, 64)])
+def test_runs_that_cross_block_boundaries(W, N, d, compute, monkeypatch):
+    """The key stages of [char | back | content] cut into W equal runs: W = 1 makes one workgroup walk
+    all three blocks, W = 2, 4, 5, 7 put run boundaries inside blocks, so blocks are cut into different
+    numbers of segments (unused partial slots) and workgroups switch query image, scale and min
+    tracking between segments.  The rows must not depend on W."""
+    monkeypatch.setenv("SID_TUNE_W", str(W))
+    H = 8
+    t = synth.attention_inputs(4600 + W, H, N, d, 1.0, 1.0, 1)
+    m = np.sign(synth.normal(4601, (N,))).astype(np.float32)
+    out = run(t, m, 0.75, 1.5, d ** -0.5, H, compute)[0]
+    rows = np.arange(0, N, 11)
+    assert np.isfinite(out).all()
+    assert rel_err(out[rows], oracle_rows(rows, t, m, 0.75, 1.5, d ** -0.5)) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Nq,Nk,d,layout", [(2, 256, 256, 160, "bnhd"), (3, 64, 64, 160, "bhnd"), (1, 70, 200, 20, "bnhd"),
                                               (2, 40, 256, 100, "bhnd"), (1, 256, 129, 8, "bnhd")])

@@ -36,3 +36,26 @@ print("  end time spread        first %.2f us last %.2f us" % ((t[:, 5].min() - 
 steady = (t[:, 3] - t[:, 2]) * 10e-9
 ok = steady > 0
 print("  shader clock in the steady loop: %.2f GHz (mean over workgroups), cycles per workgroup %.0f" % ((cyc[ok] / steady[ok]).mean() / 1e9, cyc[ok].mean()))
+# per-run breakdown (the mapping of the kernel: ids equal mod 8 share a (head, run) group)
+W = int(os.environ.get("SID_TUNE_W", "0"))
+if W:
+    QT, NW = (2, 4) if d <= 48 else (1, 4)
+    nQG = -(-(-(-N // 32) // QT) // NW)
+    groups = B * H * W
+    ids = np.arange(len(t))
+    grp = np.where(groups % 8 == 0, (ids & 7) + 8 * ((ids >> 3) // nQG), ids // nQG)
+    run = grp % W
+    life = (t[:, 5] - t[:, 0]) / 100
+    for w in range(W):
+        sel = run == w
+        print("  run %d: %d workgroups, lifetime mean %.2f us (min %.2f max %.2f), last segment's steady loop mean %.2f us" % (
+            w, sel.sum(), life[sel].mean(), life[sel].min(), life[sel].max(), ((t[sel, 3] - t[sel, 2]) / 100).mean()))
+    xcd = ids & 7
+    for x in range(8):
+        sel = xcd == x
+        print("  xcd %d: %d workgroups, lifetime mean %.2f us (min %.2f max %.2f), end of last %.2f us" % (
+            x, sel.sum(), life[sel].mean(), life[sel].min(), life[sel].max(), (t[sel, 5].max() - t0) / 100))
+    if os.environ.get("SID_DIAG_DUMP"):
+        sel = np.where(xcd == 0)[0]
+        print("  xcd 0 workgroups in id order: (start us, lifetime us)")
+        print("   " + " ".join("%.0f/%.0f" % ((t[i, 0] - t0) / 100, life[i]) for i in sel))

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_issue2.hip -o exp/ubench_issue2 && exp/ubench_issue2
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -11,7 +12,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define MFMA32(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MFMA16(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
-enum { ADD = 0, EXP = 1, CVT = 2, MAX3 = 3, PKADD = 4, MOV = 5 };
+enum { ADD = 0, EXP = 1, CVT = 2, MAX3 = 3, PKADD = 4, MOV = 5, DSREAD = 6, DSREAD64 = 7 };
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 template <int OP>
 __device__ __forceinline__ void vop(float& x, float y, float z) {
@@ -37,13 +40,33 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     for (int i = 0; i < 16; ++i) x[i] = -0.001f * (threadIdx.x + i);
     float y = 0.5f, z = 0.25f;
     asm volatile("" : "+v"(y), "+v"(z));
+    __shared__ u32x4 smem[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) smem[i] = u32x4{1u, 2u, 3u, 4u};
+    __syncthreads();
+    const unsigned laddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024;
+    u32x4 dsr[4];
+    u32x2 dsr2[4];
+    for (int i = 0; i < 4; ++i) { dsr[i] = u32x4{0u, 0u, 0u, 0u}; dsr2[i] = u32x2{0u, 0u}; }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             if (MF == 1) MFMA32(acc[g & 3]);
             if (MF == 2) MFMA16(acc4[g & 3]);
+            if (MF == 3) {   // four exponentials (about 28 issue cycles of vector work) instead of an MFMA
+                asm volatile("v_exp_f32 %0, %0" : "+v"(x[0])); asm volatile("v_exp_f32 %0, %0" : "+v"(x[1]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(x[2])); asm volatile("v_exp_f32 %0, %0" : "+v"(x[3]));
+            }
+            if (MF == 4) {   // eight max3 (about 32 issue cycles)
 #pragma unroll
-            for (int k = 0; k < K; ++k) vop<OP>(x[(g * K + k) & 15], y, z);
+                for (int q = 0; q < 8; ++q) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[q]) : "v"(y), "v"(z));
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (OP == DSREAD) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dsr[(g * K + k) & 3]) : "v"(laddr));
+                else if (OP == DSREAD64) asm volatile("ds_read_b64 %0, %1 offset:8192" : "=v"(dsr2[(g * K + k) & 3]) : "v"(laddr));
+                else vop<OP>(x[(g * K + k) & 15], y, z);
+            }
+            if (OP == DSREAD || OP == DSREAD64) { if ((g & 3) == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15");
@@ -53,6 +76,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
         for (int i = 0; i < 4; ++i) s += acc4[c][i];
     }
     for (int i = 0; i < 16; ++i) s += x[i];
+    for (int i = 0; i < 4; ++i) s += (float)(dsr[i][0] + dsr[i][3] + dsr2[i][0]);
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -94,6 +118,13 @@ int main() {
     for (int i = 0; i < 3; ++i) run<1, 0, ADD>(256);
     g_ghz = 32.0 / run<1, 0, ADD>(256);
     printf("clock from MFMA calibration: %.2f GHz\n", g_ghz);
+    sweep<0, DSREAD>("no mfma + ds_read_b128");
+    sweep<1, DSREAD>("mfma32 + ds_read_b128");
+    sweep<0, DSREAD64>("no mfma + ds_read_b64");
+    sweep<1, DSREAD64>("mfma32 + ds_read_b64");
+    sweep<3, DSREAD>("4 exp + ds_read_b128");
+    sweep<4, DSREAD>("8 max3 + ds_read_b128");
+    return 0;
     sweep<0, ADD>("no mfma + add");
     sweep<0, EXP>("no mfma + exp");
     sweep<0, CVT>("no mfma + cvt_pk");
