@@ -470,11 +470,12 @@ struct StagePipe {
 // with the compute it is meant to overlap).  The kernel waits for these loads itself
 // (wait_direct_loads) before the barrier that publishes a stage.
 __device__ __forceinline__ void glds16(const u32x4* src_uniform, unsigned lane_bytes, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    // m0 carries the LDS address of the load; it is declared clobbered (nothing else in these kernels
+    // uses it), which saves a save/restore pair of scalar instructions per load
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
                  : "v"(lane_bytes), "s"(src_uniform), "s"(lds_addr)
-                 : "memory");
+                 : "memory", "m0");
 }
 __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -606,6 +607,27 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
             wait_direct_loads();                  // (nothing to wait for after the prologue)
             __syncthreads();
             pipe.begin(lds + (it0 % NB) * SU, lane, qf);
+            // The copies issued inside the loop go through running pointers (one per unit this wave
+            // copies): a handful of scalar adds per stage instead of the full address arithmetic of
+            // issue_stage -- scalar instructions cost issue slots the loop does not have to spare.
+            constexpr int NKL = (KUn + NW - 1) / NW, NVL = (VUn + NW - 1) / NW;
+            const u32x4* rp[NKL + NVL];
+            unsigned ro[NKL + NVL];           // byte offset of the unit within a stage buffer
+            {
+                const int nx = min(it0 + NB, slen - 1);
+#pragma unroll
+                for (int i = 0; i < NKL; ++i) {
+                    const int un = min(wave + i * NW, KUn - 1);
+                    rp[i] = gk + (size_t)(st0 + nx) * KU + un * 64;
+                    ro[i] = un * 1024;
+                }
+#pragma unroll
+                for (int i = 0; i < NVL; ++i) {
+                    const int un = min(wave + i * NW, VUn - 1);
+                    rp[NKL + i] = gv + (size_t)(st0 + nx) * VU + un * 64;
+                    ro[NKL + i] = (KU + un * 64) * 16;
+                }
+            }
             for (int it = it0; it < it1; ++it) {
                 const u32x4* L = lds + (it % NB) * SU;
                 const u32x4* Ln = lds + ((it + 1) % NB) * SU;
@@ -614,7 +636,16 @@ __global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
                 __syncthreads();
                 // unconditional (no branch in the loop body): past the end the last stage is copied again
                 // into the buffer that has just become free, which nothing reads
-                issue_stage(st0 + min(it + NB, slen - 1), it % NB);
+                {
+                    const unsigned bb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((it % NB) * SU) * 16);
+                    const bool more = it + 1 + NB < slen;
+                    const int stepk = more ? KU : 0, stepv = more ? VU : 0;
+#pragma unroll
+                    for (int i = 0; i < NKL + NVL; ++i) {
+                        glds16(rp[i], lane_bytes, bb + ro[i]);
+                        rp[i] += i < NKL ? stepk : stepv;
+                    }
+                }
                 pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
             }
             pipe.finish(O);

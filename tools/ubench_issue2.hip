@@ -124,7 +124,6 @@ int main() {
     sweep<1, DSREAD64>("mfma32 + ds_read_b64");
     sweep<3, DSREAD>("4 exp + ds_read_b128");
     sweep<4, DSREAD>("8 max3 + ds_read_b128");
-    return 0;
     sweep<0, ADD>("no mfma + add");
     sweep<0, EXP>("no mfma + exp");
     sweep<0, CVT>("no mfma + cvt_pk");

@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_slot.hip -o exp/ubench_slot && exp/ubench_slot
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -20,6 +21,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 //               2 = vector ops read private registers instead of the logits (no MFMA->VALU dependency)
 //               4 = cvt writes private registers instead of P (no VALU->MFMA dependency)
 //               8 = no vector ops at all          16 = no MFMAs at all
+//               32 = plus the kernel's LDS fragment reads (14 ds_read_b128 per stage, waited for one slot later)
+//               64 = plus a workgroup barrier per stage
+//               128 = plus about 60 scalar instructions per stage (address arithmetic, loop control)
 template <int VARIANT>
 __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     f32x16 O0, O1, SA, SB, SX, SY;
@@ -32,8 +36,24 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     }
     float priv[16], e[16], m = 0.f;
     for (int i = 0; i < 16; ++i) { priv[i] = -0.01f * i; e[i] = 0.f; }
+    __shared__ u32x4 smem[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) smem[i] = u32x4{1u, 2u, 3u, 4u};
+    __syncthreads();
+    const unsigned laddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (threadIdx.x & 63) * 16;
+    u32x4 fr[7];
+    for (int i = 0; i < 7; ++i) fr[i] = u32x4{0u, 0u, 0u, 0u};
+    unsigned sc0 = blockIdx.x, sc1 = 3;
+    auto ldsread = [&](int i, int off) {
+        if (VARIANT & 32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[i]) : "v"(laddr), "n"(0) : "memory");
+        (void)off;
+    };
+    auto salu = [&](int n) {
+        if (VARIANT & 128)
+            for (int i = 0; i < n; ++i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc0) : "s"(sc1) : "scc");
+    };
 
-    auto slot = [&](f32x16& Sc, f32x16& Sn, u32x4 (&Pc)[2], u32x4 (&Pp)[2]) {
+    auto slot = [&](f32x16& Sc, f32x16& Sn, u32x4 (&Pc)[2], u32x4 (&Pp)[2], int u) {
+        if (VARIANT & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         auto src = [&](int i) -> float { return (VARIANT & 2) ? priv[i] : Sc[i]; };
         auto chunk = [&](int c) {
             if (VARIANT & 8) return;
@@ -51,6 +71,8 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
         const bool mf = !(VARIANT & 16);
         if (mf) MFMA_ACC(O0, vf[0], Pp[0]); chunk(0);
         if (mf) MFMA_ACC(O1, vf[1], Pp[0]); chunk(1);
+        if (!(u & 1)) { ldsread(3, 0); ldsread(4, 0); }
+        salu(5);
         if (VARIANT & 1) {
             if (mf) MFMA_ZERO(Sn, kf[0], qf[0]); chunk(2);
             if (mf) MFMA_ZERO(SX, kf[1], qf[1]); chunk(3);
@@ -60,17 +82,24 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
             if (mf) MFMA_ACC(Sn, kf[1], qf[1]); chunk(3);
             if (mf) MFMA_ACC(Sn, kf[2], qf[2]); chunk(4);
         }
+        if (!(u & 1)) { ldsread(0, 0); ldsread(1, 0); ldsread(2, 0); }
+        salu(5);
         if (mf) MFMA_ACC(O0, vf[2], Pp[1]); chunk(5);
         if (mf) MFMA_ACC(O1, vf[3], Pp[1]); chunk(6);
+        if (!(u & 1)) { ldsread(5, 0); ldsread(6, 0); }
+        salu(5);
     };
     for (int it = 0; it < iters; ++it) {
-        slot(SA, SB, PA, PB);
-        slot(SB, SA, PB, PA);
-        slot(SA, SB, PA, PB);
-        slot(SB, SA, PB, PA);
+        slot(SA, SB, PA, PB, 0);
+        slot(SB, SA, PB, PA, 1);
+        slot(SA, SB, PA, PB, 2);
+        if (VARIANT & 64) __syncthreads();
+        slot(SB, SA, PB, PA, 3);
     }
     asm volatile("s_nop 15\n\ts_nop 15");
     float s = m;
+    for (int i = 0; i < 7; ++i) s += (float)(fr[i][0] + fr[i][3]);
+    s += (float)sc0;
     for (int i = 0; i < 16; ++i) s += O0[i] + O1[i] + SA[i] + SB[i] + SX[i] + SY[i] + e[i] + priv[i];
     for (int j = 0; j < 2; ++j)
         for (int i = 0; i < 4; ++i) s += (float)(PA[j][i] + PB[j][i] + PX[j][i]);
@@ -97,6 +126,7 @@ void run(const char* name) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     (void)hipMalloc(&g_out, 256 * 512 * sizeof(float));
     run<8>("MFMAs only (28 per stage)");
     run<16>("vector ops only");
@@ -106,5 +136,11 @@ int main() {
     run<4>("  cvt into private registers");
     run<6>("  both (no MFMA<->VALU dependencies)");
     run<7>("  no dependencies at all");
+    run<32>("slot + LDS fragment reads");
+    run<64>("slot + barrier per stage");
+    run<128>("slot + 60 scalar instructions per stage");
+    run<32 + 64 + 128>("slot + all three");
+    run<32 + 8>("LDS reads + MFMAs only");
+    run<32 + 16>("LDS reads + vector ops only");
     return 0;
 }
