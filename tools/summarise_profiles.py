@@ -55,3 +55,26 @@ if flash and "FETCH_SIZE" in flash:
     json.dump(js, open(os.path.join(dst, tag + "_flash_traffic.json"), "w"), indent=1)
     print(js)
 print("\n".join(lines[:60]))
+# microbenchmarks and diagnostic-build runs (tools/collect_micro.sh)
+import shutil
+for name in ("micro_issue.txt", "micro_slot.txt", "micro_diag.txt"):
+    if os.path.isfile(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, tag + "_" + name))
+# matrix-pipe occupancy in shader cycles: GRBM_GUI_ACTIVE does not tick at the shader clock, so take
+# the kernel's duration from the kernel trace and the shader clock the diagnostic build measured
+try:
+    dur = None
+    for r in csv.DictReader(open(os.path.join(src, "attn", "attn_kernel_stats.csv"))):
+        if "flash_kernel" in r["Name"]:
+            dur = float(r["AverageNs"]) * 1e-9
+    m = re.search(r"shader clock in the steady loop: ([0-9.]+) GHz", open(os.path.join(src, "micro_diag.txt")).read())
+    if dur and m and flash:
+        ghz = float(m.group(1))
+        busy = flash["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (dur * ghz * 1e9)
+        with open(os.path.join(dst, tag + "_attn4096_pmc.txt"), "a") as f:
+            f.write("              in shader cycles: kernel %.1f us (kernel trace) x %.2f GHz (diagnostic build, steady loop) = %.0f cycles;\n"
+                    "              matrix-pipe busy = %.3f, i.e. %.0f MFMA cycles per SIMD (32 per 32x32x16 MFMA)\n"
+                    % (dur * 1e6, ghz, dur * ghz * 1e9, busy, flash["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024))
+        print("mfma busy (shader cycles)", busy)
+except Exception as e:   # the summaries above do not depend on this
+    print("no shader-cycle occupancy:", e)
