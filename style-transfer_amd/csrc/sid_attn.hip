@@ -440,6 +440,22 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
 }
 
+extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[8]) {
+    int rc = check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute);
+    if (rc != SID_OK) return rc;
+    SID_CHECK_ARG(blocks == 1 || blocks == kBlocks, "blocks must be 1 or %d (got %d)", kBlocks, blocks);
+    SID_CHECK_ARG(blocks == 1 || Nq == Nk, "the injected attention has Nq == Nk");
+    SID_CHECK_ARG(plan != nullptr, "NULL plan");
+    for (int i = 0; i < 8; ++i) plan[i] = 0;
+    if (blocks == 1 && use_small_path(Nk, d)) return SID_OK;
+    Geometry g;
+    rc = make_geometry(B, H, Nq, Nk, d, blocks, compute == SID_COMPUTE_F32X3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
+    if (rc != SID_OK) return rc;
+    plan[0] = g.W; plan[1] = g.G; plan[2] = g.SPB; plan[3] = g.KS; plan[4] = g.NW; plan[5] = g.QT; plan[6] = g.nQG;
+    plan[7] = g.KVS * 32;
+    return SID_OK;
+}
+
 extern "C" size_t sid_plain_attn_workspace_bytes(int B, int H, int Nq, int Nk, int d, int compute) {
     Geometry g;
     if (check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute) != SID_OK) return 0;

@@ -102,3 +102,49 @@ def test_cross_attention_shim_signature_matches_reference():
     import torch
     with pytest.raises(TypeError):                       # cnt_name=None fails like the reference does
         m(torch.zeros(1, 64, 320))
+
+
+def _plan(blocks, B, H, Nq, Nk, d, compute=0, flags=0):
+    import ctypes
+    from style_transfer_amd import lib
+    out = (ctypes.c_int * 8)()
+    lib.check(lib.load().sid_attn_plan(blocks, B, H, Nq, Nk, d, compute, flags, out))
+    return dict(zip(("W", "G", "SPB", "KS", "NW", "QT", "nQG", "stage_keys"), out))
+
+
+def test_attention_plan_covers_every_stage_once():
+    """The decomposition the flash kernel runs: the blocks' key stages form one sequence cut into W runs
+    of G stages.  Every stage must belong to exactly one run, no run may be empty, and KS must be the
+    largest number of segments any block is cut into (the partial slots the workspace holds)."""
+    shapes = [(3, 1, 8, 4096, 4096, 40), (3, 2, 8, 4096, 4096, 40), (3, 4, 8, 4096, 4096, 40), (3, 16, 8, 4096, 4096, 40),
+              (3, 1, 8, 1024, 1024, 80), (3, 1, 8, 1000, 1000, 40), (3, 1, 8, 16384, 16384, 40), (3, 1, 8, 300, 300, 160),
+              (1, 1, 8, 4096, 4096, 40), (1, 2, 8, 1024, 1024, 80), (1, 1, 8, 4096, 700, 64), (3, 1, 1, 64, 64, 40)]
+    for blocks, B, H, Nq, Nk, d in shapes:
+        for compute in (0, 1):
+            for flags in (0, 2):
+                p = _plan(blocks, B, H, Nq, Nk, d, compute, flags)
+                T = blocks * p["SPB"]
+                assert p["SPB"] == -(-Nk // p["stage_keys"])
+                assert p["W"] >= 1 and p["W"] * p["G"] >= T > (p["W"] - 1) * p["G"], p
+                segs = [len({s // p["G"] for s in range(b * p["SPB"], (b + 1) * p["SPB"])}) for b in range(blocks)]
+                assert p["KS"] == max(segs), (p, segs)
+                assert p["nQG"] * p["NW"] * p["QT"] * 32 >= Nq
+                if flags & 2:
+                    assert p["W"] == blocks and p["KS"] == 1        # concurrent callers: one run per block
+
+
+def test_attention_plan_of_the_headline_shapes():
+    """N = 4096, d = 40 (the 64x64 levels of the UNet): 512 workgroups of 48 stages at B = 1 (two per CU),
+    one workgroup per (head, query group) walking all three blocks from B = 4 on."""
+    p = _plan(3, 1, 8, 4096, 4096, 40)
+    assert (p["W"], p["G"], p["KS"], p["NW"], p["QT"], p["nQG"]) == (4, 48, 2, 4, 2, 16)
+    p = _plan(3, 4, 8, 4096, 4096, 40)
+    assert (p["W"], p["G"], p["KS"]) == (1, 192, 1)
+    p = _plan(3, 1, 8, 1024, 1024, 80)
+    assert (p["W"], p["G"], p["KS"], p["QT"]) == (3, 16, 1, 1)
+    assert _plan(1, 1, 8, 256, 77, 160)["W"] == 0                  # the short-sequence kernel has no plan
+    from style_transfer_amd import lib
+    import ctypes
+    out = (ctypes.c_int * 8)()
+    assert lib.load().sid_attn_plan(2, 1, 8, 64, 64, 40, 0, 0, out) != 0
+    assert lib.load().sid_attn_plan(3, 1, 8, 64, 32, 40, 0, 0, out) != 0
