@@ -172,8 +172,8 @@ def cpu_baseline(seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the feature tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
