@@ -235,7 +235,9 @@ def test_full_size_style_swap_symmetry(B, N, d):
     a = run(t, m, 0.75, 1.5, d ** -0.5, H, "fp32")
     t2 = dict(t, k1=t["k2"], v1=t["v2"], k2=t["k1"], v2=t["v1"])
     b = run(t2, -m, 0.75, 1.5, d ** -0.5, H, "fp32")
-    assert rel_err(a, b) < 1e-5
+    # not bit-equal: the runs may cut the char and back blocks at different stages, so the two calls sum
+    # the same terms in different orders (1.3e-5 measured with seven runs forced, 4e-6 by default)
+    assert rel_err(a, b) < 5e-5
 
 
 @pytest.mark.parametrize("B,N,d", FULL)
