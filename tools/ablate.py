@@ -11,7 +11,7 @@ from style_transfer_amd import ops
 full = bench.run_image
 
 
-def variant(extra_flags=0, plain=True, hf=True, inj=(True, True)):
+def variant(extra_flags=0, plain=True, hf=True, inj=(True, True), plain_keep=lambda N: True):
     state = {"calls": 0}
 
     def run(w, compute, flags=0):
@@ -25,6 +25,8 @@ def variant(extra_flags=0, plain=True, hf=True, inj=(True, True)):
         for e in range(bench.EVALS):
             if plain:
                 for p in w["plain"]:
+                    if not plain_keep(p["N"]):
+                        continue
                     ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, bench.HEADS, compute=compute,
                                         flags=flags | extra_flags)
             hf_on = e >= bench.EVALS - bench.HF_EVALS
@@ -45,6 +47,9 @@ def variant(extra_flags=0, plain=True, hf=True, inj=(True, True)):
 lanes = os.environ.get("ABLATE_LANES", "3")
 CASES = [("everything", full), ("no merge stage", variant(0x30)), ("no pack stage", variant(0x60)),
          ("flash stage only", variant(0x20)), ("no plain attentions", variant(0, plain=False)),
+         ("no plain N=4096", variant(0, plain_keep=lambda N: N != 4096)),
+         ("no plain N=1024", variant(0, plain_keep=lambda N: N != 1024)),
+         ("no plain N<=256", variant(0, plain_keep=lambda N: N > 256)),
          ("no HF sums", variant(0, hf=False)), ("only N=4096 injected", variant(0, plain=False, hf=False, inj=(True, False))),
          ("only N=4096 injected, flash only", variant(0x20, plain=False, hf=False, inj=(True, False)))]
 lanes = os.environ.get("ABLATE_LANES", "3")
