@@ -289,7 +289,7 @@ def main():
                        "launch": ("kernel by kernel" if args.no_graph else "one HIP graph per image") if graph_error is None
                        else "kernel by kernel (graph capture failed: %s)" % graph_error[:120],
                        "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,4,true> injected attention N=4096 d=40 H=8 B=1",
+            "roofline": {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true> injected attention N=4096 d=40 H=8 B=1",
                          "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK, "traffic": measured_traffic(), "kernel_ms": t_flash * 1e3,
                          "algorithmic_flop": flops},

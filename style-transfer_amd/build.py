@@ -15,7 +15,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the VGPRs the VALU softmax reads and rescales;
 # without it hipcc parks them in AGPRs and copies 16 registers in and out around every MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function",
+         "-Wno-inline-asm"]      # the stage copy declares m0 clobbered on purpose (see glds16)
 
 
 def _stale(target, deps):

@@ -7,10 +7,11 @@
 //               stored transposed in fragment order.  The fragment image of a 32-key tile is
 //               exactly what a wave's lanes read, so the main kernel copies it to LDS verbatim
 //               and reads it back with conflict-free lane-linear ds_read_b128.
-//   2. flash  : one workgroup per (head, part, group of query tiles), a part being a key block or
-//               a key range of one.  Each wave runs a flash-style pass over the part's keys
-//               (sid_attn_kernel.hpp) for its query tiles and writes an un-normalised partial
-//               plus the raw row max/min of q.k that the mask bias needs.
+//   2. flash  : the key stages of all blocks of a head form one sequence cut into equal runs; one
+//               workgroup per (head, run, group of query tiles).  Each wave runs a flash-style pass
+//               over the run's keys (sid_attn_kernel.hpp) for its query tiles and writes, per block
+//               segment of the run, an un-normalised partial plus the raw row max/min of q.k that
+//               the mask bias needs.
 //   3. merge  : per query row, turns the statistics into the two bias terms
 //               b = (min_j cc - max_j q.k_b) * (mask*ch_b) and combines the parts' partials into
 //               the softmax over the concatenated keys.  Skipped when there is a single part
@@ -202,8 +203,11 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     const int qwaves = (g->NQT + g->QT - 1) / g->QT;      // waves that cover the queries of one (head, part)
 
     // waves per workgroup: as many as there are query waves, up to 4, so each staged K/V tile is
-    // shared by up to 4*QT*32 queries
-    int nw = 4;
+    // shared by up to 4*QT*32 queries; 8 (both waves of every SIMD from ONE workgroup, one workgroup
+    // per CU) where that still leaves 8 query groups per head: the stage copy is shared by twice as
+    // many waves and the two waves of a SIMD advance together instead of the older workgroup
+    // starving the younger one (measured: 2-4 % at N >= 4096, a loss at N = 1024)
+    int nw = qwaves >= 64 ? 8 : 4;
     while (nw > 1 && qwaves < nw) nw >>= 1;
     if (const char* e = getenv("SID_TUNE_NW")) nw = atoi(e);
     g->NW = nw;
@@ -223,7 +227,7 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     };
     int W = nblk;
     if (!throughput) {
-        const long long pairs = BH * g->nQG, slots = 512LL * 4 / nw;
+        const long long pairs = BH * g->nQG, slots = 512LL * 4 / nw;      // two waves per SIMD
         double best = 1e30;
         for (int w = 1; w <= 8 * nblk && w <= T; ++w) {
             const int G_ = (T + w - 1) / w;

@@ -482,7 +482,7 @@ __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vm
 // SHIFT: the kShifted steady state (head_dim % 16 == 8); a separate instance rather than a run-time
 // branch, because a kernel that carries both steady-state loops no longer fits its registers.
 template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT>
-__global__ void __launch_bounds__(NW * 64, 2) flash_kernel(FlashParams P) {
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashParams P) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     constexpr int KU = KVS * DKS * 64;        // u32x4 per stage: K image
     constexpr int VU = KVS * 2 * DVB * 64;    //                  V image
@@ -871,6 +871,7 @@ int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stre
 template <int DKS, int DVB, bool X3, bool SHIFT>
 int launch_flash_nw(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     switch (g.NW) {
+        case 8: return launch_flash_inst<DKS, DVB, X3, 8, SHIFT>(fp, g, stream);
         case 4: return launch_flash_inst<DKS, DVB, X3, 4, SHIFT>(fp, g, stream);
         case 2: return launch_flash_inst<DKS, DVB, X3, 2, SHIFT>(fp, g, stream);
         default: return launch_flash_inst<DKS, DVB, X3, 1, SHIFT>(fp, g, stream);

@@ -104,10 +104,10 @@ def test_cross_attention_shapes(Nq, Nk, d, compute, path, monkeypatch):
     assert rel_err(out, ref) < TOL[compute]
 
 
-@pytest.mark.parametrize("ks,nw", [(3, 1), (2, 2), (5, 4), (8, 4)])
+@pytest.mark.parametrize("ks,nw", [(3, 1), (2, 2), (5, 4), (8, 4), (2, 8)])
 def test_forced_key_splits_and_workgroup_widths(ks, nw, monkeypatch):
     """Every decomposition gives the same rows: key ranges split over several workgroups (merged by
-    statistics) and 1/2/4 waves sharing a stage."""
+    statistics) and 1/2/4/8 waves sharing a stage."""
     monkeypatch.setenv("SID_TUNE_KS", str(ks))
     monkeypatch.setenv("SID_TUNE_NW", str(nw))
     H, N, d = 8, 1000, 40            # ragged: 31.25 key tiles

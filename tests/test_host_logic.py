@@ -134,10 +134,10 @@ def test_attention_plan_covers_every_stage_once():
 
 
 def test_attention_plan_of_the_headline_shapes():
-    """N = 4096, d = 40 (the 64x64 levels of the UNet): 512 workgroups of 48 stages at B = 1 (two per CU),
+    """N = 4096, d = 40 (the 64x64 levels of the UNet): 256 eight-wave workgroups of 48 stages at B = 1 (one per CU),
     one workgroup per (head, query group) walking all three blocks from B = 4 on."""
     p = _plan(3, 1, 8, 4096, 4096, 40)
-    assert (p["W"], p["G"], p["KS"], p["NW"], p["QT"], p["nQG"]) == (4, 48, 2, 4, 2, 16)
+    assert (p["W"], p["G"], p["KS"], p["NW"], p["QT"], p["nQG"]) == (4, 48, 2, 8, 2, 8)
     p = _plan(3, 4, 8, 4096, 4096, 40)
     assert (p["W"], p["G"], p["KS"]) == (1, 192, 1)
     p = _plan(3, 1, 8, 1024, 1024, 80)

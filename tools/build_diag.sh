@@ -4,7 +4,7 @@
 set -e
 mkdir -p exp
 OBJ=style-transfer_amd/csrc/_obj
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DSID_DIAG"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -Wno-inline-asm -DSID_DIAG"
 for u in sid_attn sid_attn_bf16 sid_attn_x3; do
   /opt/rocm/bin/hipcc $F -c style-transfer_amd/csrc/$u.hip -o exp/d_$u.o &
 done

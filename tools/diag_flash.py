@@ -39,7 +39,8 @@ print("  shader clock in the steady loop: %.2f GHz (mean over workgroups), cycle
 # per-run breakdown (the mapping of the kernel: ids equal mod 8 share a (head, run) group)
 W = int(os.environ.get("SID_TUNE_W", "0"))
 if W:
-    QT, NW = (2, 4) if d <= 48 else (1, 4)
+    QT = 2 if d <= 48 else 1
+    NW = 8 if -(-(-(-N // 32)) // QT) >= 64 else 4
     nQG = -(-(-(-N // 32) // QT) // NW)
     groups = B * H * W
     ids = np.arange(len(t))
