@@ -1,4 +1,4 @@
-# A/B of two library builds on one box: exp/old.so (previous kernel) against the in-tree build.
+# A/B of two library builds on one box: exp/old.so (build it from an earlier commit: git archive + hipcc, see tools/build_exp.sh) against the in-tree build.
 for lib in old new; do
   if [ $lib = old ]; then export SID_LIB_OVERRIDE=$PWD/exp/old.so; else unset SID_LIB_OVERRIDE; fi
   echo -n "$lib 4096/40 B=1: "; timeout -k 10 60 python3 tools/prof_attn.py 4096 40 1 50 2>/dev/null || exit 1
