@@ -666,23 +666,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         qf[t].hi[DKS - 1] = as_bf16x8(w);
     };
 
+    // images and query fragments of a block
+    auto enter_block = [&](int b_) {
+        gk = P.k[b_] + (size_t)bh * P.NKT * DKS * 64;
+        gv = P.v[b_] + (size_t)bh * P.NKT * 2 * DVB * 64;
+        gkl = X3 ? P.k_lo[b_] + (size_t)bh * P.NKT * DKS * 64 : nullptr;
+        gvl = X3 ? P.v_lo[b_] + (size_t)bh * P.NKT * 2 * DVB * 64 : nullptr;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qt = min(qt0 + t, P.NQT - 1);
+            qf[t].load(P.q[b_] + ((size_t)(bh * P.NQT + qt) * DKS) * 64 + lane,
+                       X3 ? (int)(P.q_lo[b_] - P.q[b_]) : 0);
+        }
+    };
+    // A segment that is followed by another one requests that segment's first stages and query
+    // fragments before it stores its own results, so their latency passes behind the store.
+    int prefetched = 0;               // stages of the segment about to start that are already issued
+
     for (blk = g0 / P.SPB; blk * P.SPB < g1; ++blk) {
     st0 = max(g0 - blk * P.SPB, 0);
     slen = min(g1 - blk * P.SPB, P.SPB) - st0;
     const int first_run = (blk * P.SPB) / P.G;               // the run that holds the block's first stage
     part = blk * P.KS + (run_w - first_run);
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int qt = min(qt0 + t, P.NQT - 1);
-        qf[t].load(P.q[blk] + ((size_t)(bh * P.NQT + qt) * DKS) * 64 + lane,
-                   X3 ? (int)(P.q_lo[blk] - P.q[blk]) : 0);
-    }
+    if (!prefetched) enter_block(blk);
     c2 = P.c2[blk];
     need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || c2 < 0.f;
-    gk = P.k[blk] + (size_t)bh * P.NKT * DKS * 64;
-    gv = P.v[blk] + (size_t)bh * P.NKT * 2 * DVB * 64;
-    gkl = X3 ? P.k_lo[blk] + (size_t)bh * P.NKT * DKS * 64 : nullptr;
-    gvl = X3 ? P.v_lo[blk] + (size_t)bh * P.NKT * 2 * DVB * 64 : nullptr;
     if (tid == 0) redo = 0;           // published by the barrier of the prologue below
 
     // stages of this segment that hold only valid keys (the rest are tails)
@@ -703,8 +711,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         }
         // the first NB stages start together: their latencies (and that of the query fragments above)
         // overlap
-        nissued = min(NB, slen);
-        for (int k = 0; k < nissued; ++k) issue_stage(st0 + k, k);
+        // (redundant stage copies the pipelined loop left in flight target the same buffers from the
+        // same waves: direct loads of a wave complete in order, so the copies issued here win)
+        if (prefetched) {
+            nissued = prefetched;
+            prefetched = 0;
+        } else {
+            nissued = min(NB, slen);
+            for (int k = 0; k < nissued; ++k) issue_stage(st0 + k, k);
+        }
         wait_direct_loads();
         __syncthreads();
 
@@ -761,7 +776,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         stamp(3);
         run(T_{}, T_{}, Online{}, nfull, slen);                      // stages with masked keys
         stamp(4);
-        wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
 
         bool over = false;
 #pragma unroll
@@ -769,6 +783,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         if (pass == 0 && __any(over) && lane == 0) redo = 1;
         __syncthreads();
         if (pass == 1 || redo == 0) break;
+    }
+    // every wave is past its last LDS read of this segment: start the next segment (it begins at
+    // stage 0 of the next block); nothing below touches LDS, the images or the query fragments
+    if ((blk + 1) * P.SPB < g1) {
+        enter_block(blk + 1);
+        prefetched = min(NB, min(g1 - (blk + 1) * P.SPB, P.SPB));
+        for (int k = 0; k < prefetched; ++k) issue_stage(k, k);
     }
 
     // ---- store: combine the two lane halves of every query column
@@ -849,6 +870,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         }
     }
     }   // segments
+    wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
     stamp(5);
 }
 
