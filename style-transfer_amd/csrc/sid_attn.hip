@@ -613,9 +613,8 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const int KSr = P.KS;
     auto blk_of = [&](int p) { return p / KSr; };
     auto bias_of = [&](int p) { const int k = blk_of(p); return k == 0 ? bias2[0] : (k == 1 ? bias2[1] : bias2[2]); };
-    auto c2_of = [&](int p) { const int k = blk_of(p); return k == 0 ? P.c2[0] : (k == 1 ? P.c2[1] : P.c2[2]); };
-    // reference of the combined softmax: the largest biased logit of the row (the true maxima, not
-    // the parts' own references, which a logit may exceed by up to 2^kOverflowThr)
+    // reference of the combined softmax: the largest log2 of a part's biased weight sum, m2 + log2(l)
+    // (not the parts' own references m2, which a logit may exceed by up to 2^kOverflowThr)
     float M2 = -SID_INF;
     float acc[VEC];
 #pragma unroll
@@ -625,8 +624,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
 #pragma unroll
         for (int p = 0; p < CAP; ++p) {
             const f32x4 st = stat(p);
-            const float cp = c2_of(p);
-            if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias_of(p));
+            if (st[1] > 0.f) M2 = fmaxf(M2, st[0] + __builtin_amdgcn_logf(st[1]) + bias_of(p));
         }
 #pragma unroll
         for (int p = 0; p < CAP; ++p) {
@@ -639,8 +637,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     } else {
         for (int p = 0; p < nparts; ++p) {
             const f32x4 st = stat(p);
-            const float cp = c2_of(p);
-            if (st[1] > 0.f) M2 = fmaxf(M2, (cp >= 0.f ? st[2] : st[3]) * cp + bias_of(p));
+            if (st[1] > 0.f) M2 = fmaxf(M2, st[0] + __builtin_amdgcn_logf(st[1]) + bias_of(p));
         }
         for (int p = 0; p < nparts; ++p) {
             const f32x4 st = stat(p);

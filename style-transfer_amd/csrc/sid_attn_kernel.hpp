@@ -35,6 +35,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte unit (a
 
 constexpr int kBlocks = 3;            // key blocks of the injected attention: char, back, content
 constexpr float kOverflowThr = 96.f;  // log2 units a logit may exceed the fixed reference by
+constexpr float kOverflowSum = 1.2676506e30f;   // 2^100: a row sum beyond it (or not a number) means the same
 #define SID_INF __builtin_huge_valf()
 
 struct FlashParams {
@@ -309,20 +310,21 @@ __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, 
 enum { kOpExp, kOpCvt, kOpMax, kOpMin, kOpUpdMax, kOpUpdMin };
 struct SoftmaxOps { int n; int kind[64]; int arg[64]; };
 // The vector ops of one unit in issue order: per pair of logits two exponentials, a step of the max
-// (and min) tree, and the bf16 packing of the previous pair.
+// OR min tree, and the bf16 packing of the previous pair.  The pipelined loop tracks exactly one
+// extreme of the logits per segment, the one the mask bias needs from it (the largest raw q.k of a
+// style block, the smallest content logit): overflow is caught from the row sums instead of from the
+// row maximum, and the merge takes its reference from the sums as well.
 constexpr SoftmaxOps softmax_ops(bool track_min) {
     SoftmaxOps t{};
     int n = 0;
     for (int g = 0; g < 8; ++g) {
         t.kind[n] = kOpExp; t.arg[n++] = 2 * g;
         t.kind[n] = kOpExp; t.arg[n++] = 2 * g + 1;
-        t.kind[n] = kOpMax; t.arg[n++] = g;
-        if (track_min) { t.kind[n] = kOpMin; t.arg[n++] = g; }
+        t.kind[n] = track_min ? kOpMin : kOpMax; t.arg[n++] = g;
         if (g > 0) { t.kind[n] = kOpCvt; t.arg[n++] = g - 1; }
     }
     t.kind[n] = kOpCvt; t.arg[n++] = 7;
-    t.kind[n] = kOpUpdMax; t.arg[n++] = 0;
-    if (track_min) { t.kind[n] = kOpUpdMin; t.arg[n++] = 0; }
+    t.kind[n] = track_min ? kOpUpdMin : kOpUpdMax; t.arg[n++] = 0;
     t.n = n;
     return t;
 }
@@ -777,9 +779,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         run(T_{}, T_{}, Online{}, nfull, slen);                      // stages with masked keys
         stamp(4);
 
+        // a logit that outgrew the fixed reference: seen in the tracked maximum, or (where only the
+        // minimum is tracked) in a row sum -- the ones column of V -- that left the safe range
         bool over = false;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) over |= rs[t].smax - rs[t].m2 > kOverflowThr;
+        for (int t = 0; t < QT; ++t) {
+            const float lrow = hh ? O[t][DVB - 1][15] : 0.f;
+            over |= rs[t].smax - rs[t].m2 > kOverflowThr || !(lrow < kOverflowSum);
+        }
         if (pass == 0 && __any(over) && lane == 0) redo = 1;
         __syncthreads();
         if (pass == 1 || redo == 0) break;
