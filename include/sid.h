@@ -97,14 +97,16 @@ int sid_injected_attn_fwd(const void* x_q, const void* q_cnt,
  * How a call would be decomposed (host arithmetic only, nothing is launched): for
  * sid_injected_attn_fwd (blocks = 3, Nq = Nk = N) or sid_plain_attn_fwd (blocks = 1) with the
  * given shape, compute mode and flags, fills
- *   plan[0] runs per (head, query group) over the blocks' key stages   plan[1] stages per run
+ *   plan[0] runs per (head, query group) over the blocks' key stages   plan[1] stages of the longest run
  *   plan[2] stages per block          plan[3] partial slots per block   plan[4] waves per workgroup
  *   plan[5] query tiles per wave      plan[6] query groups              plan[7] keys per stage
+ *   plan[8 .. 8 + plan[0]]  run boundaries: run w covers stages [plan[8 + w], plan[9 + w]) of the
+ *                           sequence of blocks * plan[2] stages (at most 24 runs)
  * or plan[0] = 0 when the short-sequence kernel takes the call (it has no decomposition).
  * No counterpart in the reference: a planning query for tests and for callers that size their own
  * stream pools.
  */
-int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[8]);
+int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]);
 
 /*
  * Single-block attention  out = softmax((q k^T) * logit_scale) v.

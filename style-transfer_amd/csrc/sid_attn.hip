@@ -239,11 +239,40 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     }
     if (const char* e = getenv("SID_TUNE_KS")) W = nblk * atoi(e);       // the same number of runs per block
     if (const char* e = getenv("SID_TUNE_W")) W = atoi(e);
-    W = std::max(1, std::min(W, T));
+    W = std::max(1, std::min(std::min(W, T), kMaxRuns));
     g->SPB = stages;
-    g->G = (T + W - 1) / W;
-    g->W = (T + g->G - 1) / g->G;                         // drop runs that would hold no stage
-    g->KS = slots_per_block(g->G);
+    g->W = W;
+    // Run boundaries: equal shares of the cost, where a run that continues into the next block pays
+    // kSwitch stages for the change (store, new query image, first stage of the new block: measured
+    // 6-7 us against 1.3 us per stage at head_dim 40).  c(s) = s + kSwitch * (block boundaries before
+    // s) is cut at its W-quantiles; a cut that falls into the cost of a change sits on the boundary.
+    constexpr double kSwitch = 5.0;
+    const double ctot = T + kSwitch * (nblk - 1);
+    g->bound[0] = 0;
+    for (int k = 1; k <= W; ++k) {
+        const double x = ctot * k / W;
+        int s = T;
+        for (int b = 0; b < nblk; ++b) {
+            const double lo = b * (stages + kSwitch);
+            if (x <= lo) { s = b * stages; break; }
+            if (x < lo + stages) { s = b * stages + (int)std::lround(x - lo); break; }
+        }
+        s = std::max(s, (int)g->bound[k - 1] + 1);       // every run holds a stage ...
+        s = std::min(s, T - (W - k));                      // ... and leaves one for each run after it
+        g->bound[k] = (unsigned short)s;
+    }
+    g->G = 0;
+    for (int k = 0; k < W; ++k) g->G = std::max(g->G, (int)g->bound[k + 1] - (int)g->bound[k]);
+    g->KS = 1;
+    for (int b = 0; b < kBlocks; ++b) { g->first_run[b] = 0; g->nseg[b] = 0; }
+    for (int b = 0; b < nblk; ++b) {
+        int first = -1, n = 0;
+        for (int k = 0; k < W; ++k)
+            if (g->bound[k] < (b + 1) * stages && g->bound[k + 1] > b * stages) { if (first < 0) first = k; ++n; }
+        g->first_run[b] = (unsigned char)first;
+        g->nseg[b] = (unsigned char)n;
+        g->KS = std::max(g->KS, n);
+    }
     g->NKT = stages * g->KVS;                             // whole stages; surplus tiles are zero
     g->lds = (size_t)ring_stages(g->DKS, g->DVB, x3) * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
     g->q_units = (size_t)BH * g->NQT * g->DKS * 64;
@@ -341,7 +370,10 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
                     hipStream_t stream) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
-    fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.G = g.G; fp.nblk = nblk; fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
+    fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.nblk = nblk;
+    for (int k = 0; k <= g.W; ++k) fp.bound[k] = g.bound[k];
+    for (int b = 0; b < kBlocks; ++b) { fp.first_run[b] = g.first_run[b]; fp.nseg[b] = g.nseg[b]; }
+    fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
 #ifdef SID_DIAG
     fp.diag = (unsigned long long*)(getenv("SID_DIAG_PTR") ? strtoull(getenv("SID_DIAG_PTR"), nullptr, 0) : 0ull);
 #endif
@@ -444,19 +476,20 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
 }
 
-extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[8]) {
+extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]) {
     int rc = check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute);
     if (rc != SID_OK) return rc;
     SID_CHECK_ARG(blocks == 1 || blocks == kBlocks, "blocks must be 1 or %d (got %d)", kBlocks, blocks);
     SID_CHECK_ARG(blocks == 1 || Nq == Nk, "the injected attention has Nq == Nk");
     SID_CHECK_ARG(plan != nullptr, "NULL plan");
-    for (int i = 0; i < 8; ++i) plan[i] = 0;
+    for (int i = 0; i < 40; ++i) plan[i] = 0;
     if (blocks == 1 && use_small_path(Nk, d)) return SID_OK;
     Geometry g;
     rc = make_geometry(B, H, Nq, Nk, d, blocks, compute == SID_COMPUTE_F32X3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
     if (rc != SID_OK) return rc;
     plan[0] = g.W; plan[1] = g.G; plan[2] = g.SPB; plan[3] = g.KS; plan[4] = g.NW; plan[5] = g.QT; plan[6] = g.nQG;
     plan[7] = g.KVS * 32;
+    for (int k = 0; k <= g.W; ++k) plan[8 + k] = g.bound[k];
     return SID_OK;
 }
 

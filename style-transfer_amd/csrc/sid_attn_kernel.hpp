@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // 16-byte unit (a native vector: stays in registers)
 
 constexpr int kBlocks = 3;            // key blocks of the injected attention: char, back, content
+constexpr int kMaxRuns = 8 * kBlocks; // runs a head's key stages are cut into, at most
 constexpr float kOverflowThr = 96.f;  // log2 units a logit may exceed the fixed reference by
 constexpr float kOverflowSum = 1.2676506e30f;   // 2^100: a row sum beyond it (or not a number) means the same
 #define SID_INF __builtin_huge_valf()
@@ -56,7 +57,10 @@ struct FlashParams {
     int nQG;                     // query groups (workgroups per (head, run))
     int KS;                      // partial slots per block (the most segments any block is cut into)
     int SPB;                     // stages per block
-    int W, G;                    // runs per (head, query group); stages per run: W * G >= nblk * SPB
+    int W;                       // runs per (head, query group) over the nblk * SPB key stages
+    unsigned short bound[kMaxRuns + 1];   // run w covers stages [bound[w], bound[w + 1]) of that sequence
+    unsigned char first_run[kBlocks];     // the run that holds a block's first stage
+    unsigned char nseg[kBlocks];          // runs that overlap a block = partial slots it uses (<= KS)
     int nblk;                    // 3: injected [char | back | content], 1: single block
     int direct;                  // single part: normalise and write `out` here, no merge kernel
     int out_bf16;
@@ -84,7 +88,9 @@ struct Geometry {
     int NW;            // waves per workgroup
     int KS;            // partial slots per block
     int SPB;           // stages per block
-    int W, G;          // runs per (head, query group) over the nblk * SPB stages, stages per run
+    int W, G;          // runs per (head, query group) over the nblk * SPB stages; stages of the longest run
+    unsigned short bound[kMaxRuns + 1];
+    unsigned char first_run[kBlocks], nseg[kBlocks];
     int NQT, NKT;      // tiles in the packed images
     int nQG;
     size_t lds;
@@ -527,10 +533,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         }
     }
     // The key stages of the nblk blocks form one sequence of nblk * SPB stages; run w of W covers
-    // stages [w * G, (w + 1) * G) of it.  Where a run crosses a block boundary the workgroup finishes
-    // one segment (its own partial output and statistics) and starts the next.
+    // stages [bound[w], bound[w + 1]) of it (the host balances the runs, counting what a change of
+    // block costs).  Where a run crosses a block boundary the workgroup finishes one segment (its own
+    // partial output and statistics) and starts the next.
     const int run_w = grp % P.W, bh = grp / P.W;
-    const int g0 = run_w * P.G, g1 = min(g0 + P.G, P.nblk * P.SPB);
+    const int g0 = P.bound[run_w], g1 = P.bound[run_w + 1];
 
     // this wave's query tiles; surplus tiles redo the last one and store nothing
     const int qt0 = (qg * NW + wave) * QT;
@@ -688,7 +695,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     for (blk = g0 / P.SPB; blk * P.SPB < g1; ++blk) {
     st0 = max(g0 - blk * P.SPB, 0);
     slen = min(g1 - blk * P.SPB, P.SPB) - st0;
-    const int first_run = (blk * P.SPB) / P.G;               // the run that holds the block's first stage
+    const int first_run = P.first_run[blk];                  // the run that holds the block's first stage
     part = blk * P.KS + (run_w - first_run);
     if (!prefetched) enter_block(blk);
     c2 = P.c2[blk];
@@ -867,8 +874,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 // a block cut into fewer segments than there are partial slots per block: the first
                 // segment marks the unused slots empty (sum 0; the merge skips them)
                 if (run_w == first_run) {
-                    const int last_run = ((blk + 1) * P.SPB - 1) / P.G;
-                    for (int pp = last_run - first_run + 1; pp < P.KS; ++pp) {
+                    for (int pp = P.nseg[blk]; pp < P.KS; ++pp) {
                         f32x4 none = {-SID_INF, 0.f, -SID_INF, SID_INF};
                         *(f32x4*)(P.stats + ((((size_t)blk * P.KS + pp) * BH + bh) * P.Nq + q) * 4) = none;
                     }

@@ -107,15 +107,18 @@ def test_cross_attention_shim_signature_matches_reference():
 def _plan(blocks, B, H, Nq, Nk, d, compute=0, flags=0):
     import ctypes
     from style_transfer_amd import lib
-    out = (ctypes.c_int * 8)()
+    out = (ctypes.c_int * 40)()
     lib.check(lib.load().sid_attn_plan(blocks, B, H, Nq, Nk, d, compute, flags, out))
-    return dict(zip(("W", "G", "SPB", "KS", "NW", "QT", "nQG", "stage_keys"), out))
+    p = dict(zip(("W", "G", "SPB", "KS", "NW", "QT", "nQG", "stage_keys"), out))
+    p["bound"] = list(out[8:9 + p["W"]])
+    return p
 
 
 def test_attention_plan_covers_every_stage_once():
     """The decomposition the flash kernel runs: the blocks' key stages form one sequence cut into W runs
-    of G stages.  Every stage must belong to exactly one run, no run may be empty, and KS must be the
-    largest number of segments any block is cut into (the partial slots the workspace holds)."""
+    at plan[8..].  The runs must tile the sequence (every stage in exactly one, none empty), G must be
+    the longest, and KS the largest number of runs any block overlaps (the partial slots the workspace
+    holds)."""
     shapes = [(3, 1, 8, 4096, 4096, 40), (3, 2, 8, 4096, 4096, 40), (3, 4, 8, 4096, 4096, 40), (3, 16, 8, 4096, 4096, 40),
               (3, 1, 8, 1024, 1024, 80), (3, 1, 8, 1000, 1000, 40), (3, 1, 8, 16384, 16384, 40), (3, 1, 8, 300, 300, 160),
               (1, 1, 8, 4096, 4096, 40), (1, 2, 8, 1024, 1024, 80), (1, 1, 8, 4096, 700, 64), (3, 1, 1, 64, 64, 40)]
@@ -124,20 +127,26 @@ def test_attention_plan_covers_every_stage_once():
             for flags in (0, 2):
                 p = _plan(blocks, B, H, Nq, Nk, d, compute, flags)
                 T = blocks * p["SPB"]
+                bd = p["bound"]
                 assert p["SPB"] == -(-Nk // p["stage_keys"])
-                assert p["W"] >= 1 and p["W"] * p["G"] >= T > (p["W"] - 1) * p["G"], p
-                segs = [len({s // p["G"] for s in range(b * p["SPB"], (b + 1) * p["SPB"])}) for b in range(blocks)]
+                assert 1 <= p["W"] <= 24 and len(bd) == p["W"] + 1 and bd[0] == 0 and bd[-1] == T, p
+                assert all(b1 > b0 for b0, b1 in zip(bd, bd[1:])), p
+                assert p["G"] == max(b1 - b0 for b0, b1 in zip(bd, bd[1:]))
+                segs = [sum(1 for b0, b1 in zip(bd, bd[1:]) if b0 < (b + 1) * p["SPB"] and b1 > b * p["SPB"])
+                        for b in range(blocks)]
                 assert p["KS"] == max(segs), (p, segs)
                 assert p["nQG"] * p["NW"] * p["QT"] * 32 >= Nq
-                if flags & 2:
-                    assert p["W"] == blocks and p["KS"] == 1        # concurrent callers: one run per block
+                if flags & 2:                                        # concurrent callers: one run per block
+                    assert p["W"] == blocks and p["KS"] == 1 and bd == [b * p["SPB"] for b in range(blocks + 1)]
 
 
 def test_attention_plan_of_the_headline_shapes():
     """N = 4096, d = 40 (the 64x64 levels of the UNet): 256 eight-wave workgroups of 48 stages at B = 1 (one per CU),
     one workgroup per (head, query group) walking all three blocks from B = 4 on."""
     p = _plan(3, 1, 8, 4096, 4096, 40)
-    assert (p["W"], p["G"], p["KS"], p["NW"], p["QT"], p["nQG"]) == (4, 48, 2, 8, 2, 8)
+    assert (p["W"], p["KS"], p["NW"], p["QT"], p["nQG"]) == (4, 2, 8, 2, 8)
+    # a run that changes block is shorter by what the change costs: 192 stages + 2 changes in four shares
+    assert p["bound"] == [0, 51, 96, 142, 192]
     p = _plan(3, 4, 8, 4096, 4096, 40)
     assert (p["W"], p["G"], p["KS"]) == (1, 192, 1)
     p = _plan(3, 1, 8, 1024, 1024, 80)
@@ -145,6 +154,6 @@ def test_attention_plan_of_the_headline_shapes():
     assert _plan(1, 1, 8, 256, 77, 160)["W"] == 0                  # the short-sequence kernel has no plan
     from style_transfer_amd import lib
     import ctypes
-    out = (ctypes.c_int * 8)()
+    out = (ctypes.c_int * 40)()
     assert lib.load().sid_attn_plan(2, 1, 8, 64, 64, 40, 0, 0, out) != 0
     assert lib.load().sid_attn_plan(3, 1, 8, 64, 32, 40, 0, 0, out) != 0
