@@ -504,11 +504,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
 #ifdef SID_DIAG
-    // stamps 0..5: constant 100 MHz counter; 6, 7: the shader cycle counter at stamps 2 and 3 (the steady loop)
+    // 8 stamps per segment (up to 3 segments per workgroup): 0..5 from the constant 100 MHz counter,
+    // 6, 7 = the shader cycle counter at stamps 2 and 3 (the steady loop)
+    int diag_seg = 0;
     auto stamp = [&](int i) {
-        if (tid == 0 && P.diag) {
-            P.diag[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
-            if (i == 2 || i == 3) P.diag[(size_t)blockIdx.x * 8 + 4 + i] = __builtin_readcyclecounter();
+        if (tid == 0 && P.diag && diag_seg < 3) {
+            unsigned long long* dg = P.diag + ((size_t)blockIdx.x * 3 + diag_seg) * 8;
+            dg[i] = __builtin_amdgcn_s_memrealtime();
+            if (i == 2 || i == 3) dg[4 + i] = __builtin_readcyclecounter();
         }
     };
     stamp(0);
@@ -882,9 +885,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
             }
         }
     }
+    stamp(5);
+#ifdef SID_DIAG
+    ++diag_seg;
+    stamp(0);
+#endif
     }   // segments
     wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
-    stamp(5);
 }
 
 template <int DKS, int DVB, bool X3, int NW, bool SHIFT>

@@ -1,12 +1,12 @@
 """Diagnostic build only (exp/diag.so, -DSID_DIAG): per-workgroup clock stamps of the flash kernel.
-stamps: 0 entry, 1 first stage landed, 2 first stage done, 3 steady loop done, 4 tails done, 5 stored.
+stamps per segment: 0 start, 1 first stages landed, 2 reference pre-pass done, 3 steady loop done, 4 tails done, 5 stored.
 memrealtime ticks at 100 MHz (10 ns)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 N, d, B = (int(sys.argv[i]) if len(sys.argv) > i else v for i, v in ((1, 1024), (2, 80), (3, 1)))
 dev = torch.device("cuda:0")
-diag = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
+diag = torch.zeros(24 * 65536, dtype=torch.int64, device=dev)
 os.environ["SID_DIAG_PTR"] = str(diag.data_ptr())
 os.environ["SID_LIB_OVERRIDE"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exp", "diag.so")
 from style_transfer_amd import ops
@@ -20,10 +20,13 @@ torch.cuda.synchronize()
 diag.zero_()
 ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
 torch.cuda.synchronize()
-t = diag.cpu().numpy().reshape(-1, 8)
-t = t[t[:, 0] > 0].astype(np.float64)
-cyc = t[:, 7] - t[:, 6]
-t = t[:, :6]
+raw = diag.cpu().numpy().reshape(-1, 3, 8).astype(np.float64)      # [workgroup][segment][stamp]
+raw = raw[raw[:, 0, 0] > 0]
+nseg = (raw[:, :, 5] > 0).sum(axis=1).astype(int)                   # segments a workgroup ran
+last = raw[np.arange(len(raw)), nseg - 1]                           # the phases below are those of the last segment
+cyc = last[:, 7] - last[:, 6]
+t = last[:, :6].copy()
+t[:, 0] = raw[:, 0, 0]                                              # ... but a workgroup starts with its first
 t0 = t[:, 0].min()
 print("workgroups", len(t), " kernel span %.2f us" % ((t[:, 5].max() - t0) / 100))
 names = ["entry->stage0 landed", "first stage", "steady loop", "tails", "store"]
@@ -60,3 +63,12 @@ if W:
         sel = np.where(xcd == 0)[0]
         print("  xcd 0 workgroups in id order: (start us, lifetime us)")
         print("   " + " ".join("%.0f/%.0f" % ((t[i, 0] - t0) / 100, life[i]) for i in sel))
+    # segment by segment, for the runs that have more than one
+    for w in range(W):
+        sel = run == w
+        if nseg[sel].max() < 2:
+            continue
+        r = raw[sel]
+        for sg in range(int(nseg[sel].max())):
+            d = [(r[:, sg, i + 1] - r[:, sg, i]).mean() / 100 for i in range(5)]
+            print("  run %d segment %d: load %.2f  pre-pass %.2f  steady %.2f  tails %.2f  store %.2f us" % (w, sg, *d))
