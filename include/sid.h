@@ -94,6 +94,29 @@ int sid_injected_attn_fwd(const void* x_q, const void* q_cnt,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * sid_injected_attn_fwd for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments and results as sid_injected_attn_fwd without the workspace pair: the scratch is a
+ * static device array of SID_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
+ * process ends.  The call allocates and frees nothing (its first call on a device looks the array's
+ * address up once).  A shape whose scratch need (sid_injected_attn_workspace_bytes) exceeds the array
+ * is refused with SID_ENOMEM; 64 MiB covers B = 1, H = 8 at N = 4096, d = 40 and N = 1024, d = 80
+ * in SID_COMPUTE_BF16.  All calls on one GPU share the array: calls that overlap in time on one GPU
+ * (different streams or threads) race; serialise them, or give each stream its own workspace through
+ * sid_injected_attn_fwd.
+ */
+#define SID_STATIC_SCRATCH_BYTES (64u << 20)
+
+int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt,
+                                 const void* k1, const void* v1,
+                                 const void* k2, const void* v2,
+                                 const void* k_cnt, const void* v_cnt,
+                                 const float* mask_signed, void* out,
+                                 int B, int H, int N, int d,
+                                 float gamma, float q_self_coef, float T, float scale,
+                                 int dtype, int compute, int flags, void* stream);
+
+/*
  * How a call would be decomposed (host arithmetic only, nothing is launched): for
  * sid_injected_attn_fwd (blocks = 3, Nq = Nk = N) or sid_plain_attn_fwd (blocks = 1) with the
  * given shape, compute mode and flags, fills

@@ -20,6 +20,7 @@
 #include "sid_attn_kernel.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -405,13 +406,38 @@ extern "C" size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, 
     return bytes;
 }
 
-extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
-                                     const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
-                                     const float* mask_signed, void* out, int B, int H, int N, int d,
-                                     float gamma, float q_self_coef, float T, float scale, int dtype,
-                                     int compute, int flags, void* workspace, size_t workspace_bytes,
-                                     void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// Scratch of the entry point that allocates nothing (sid_injected_attn_fwd_static): one array per
+// GPU, part of the code object, held from the moment the library is loaded on a device until the
+// process ends.  In host code the name below is only a handle of the symbol, never a device address:
+// the address the kernels and memsets use comes from hipGetSymbolAddress, once per device (every GPU
+// has its own copy at its own address).
+static __device__ __align__(256) unsigned char scratch[SID_STATIC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
+int static_scratch(void** ptr) {
+    int dev = 0;
+    SID_CHECK_HIP(hipGetDevice(&dev));
+    SID_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "device ordinal %d is beyond the %d this library tracks", dev, kMaxDevices);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        SID_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        SID_CHECK_ARG(p != nullptr && ((uintptr_t)p & 255) == 0, "the static scratch array has no usable device address");
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *ptr = p;
+    return SID_OK;
+}
+
+int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
+                       const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
+                       const float* mask_signed, void* out, int B, int H, int N, int d,
+                       float gamma, float q_self_coef, float T, float scale, int dtype,
+                       int compute, int flags, void* workspace, size_t workspace_bytes,
+                       bool static_ws, hipStream_t stream) {
     const Stages stg(flags);
     int rc = check_common(B, H, N, N, d, dtype, compute);
     if (rc != SID_OK) return rc;
@@ -426,8 +452,13 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     if (rc != SID_OK) return rc;
     Workspace w;
     carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w);
-    if (w.bytes > workspace_bytes)
+    if (w.bytes > workspace_bytes) {
+        if (static_ws)
+            return sid::fail(SID_ENOMEM, "B=%d H=%d N=%d d=%d needs %zu bytes of scratch; the static buffer of "
+                             "sid_injected_attn_fwd_static holds %zu (use sid_injected_attn_fwd with a caller workspace)",
+                             B, H, N, d, w.bytes, workspace_bytes);
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
+    }
 
     // logit scales in the log2 domain; applied to the query images by the pack kernel
     const float c2s = clamp_scale(T * scale * LOG2E), c2c = clamp_scale(scale * LOG2E);
@@ -474,6 +505,32 @@ extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const v
     fp.c2[0] = fp.c2[1] = c2s;
     fp.c2[2] = c2c;
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
+}
+
+}  // namespace
+
+extern "C" int sid_injected_attn_fwd(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
+                                     const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
+                                     const float* mask_signed, void* out, int B, int H, int N, int d,
+                                     float gamma, float q_self_coef, float T, float scale, int dtype,
+                                     int compute, int flags, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return injected_attn_impl(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, out, B, H, N, d, gamma,
+                              q_self_coef, T, scale, dtype, compute, flags, workspace, workspace_bytes, false,
+                              (hipStream_t)stream);
+}
+
+extern "C" int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
+                                            const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
+                                            const float* mask_signed, void* out, int B, int H, int N, int d,
+                                            float gamma, float q_self_coef, float T, float scale, int dtype,
+                                            int compute, int flags, void* stream) {
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != SID_OK) return rc;
+    return injected_attn_impl(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, out, B, H, N, d, gamma,
+                              q_self_coef, T, scale, dtype, compute, flags, ws, (size_t)SID_STATIC_SCRATCH_BYTES, true,
+                              (hipStream_t)stream);
 }
 
 extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]) {

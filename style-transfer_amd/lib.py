@@ -13,6 +13,7 @@ SID_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
 COMPUTE_BF16, COMPUTE_F32X3 = 0, 1
 LAYOUT_BHND, LAYOUT_BNHD = 0, 1
+STATIC_SCRATCH_BYTES = 64 << 20
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -23,6 +24,7 @@ SIGNATURES = {
     "sid_version": (_i, []),
     "sid_injected_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sid_injected_attn_fwd": (_i, [_vp] * 8 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sid_injected_attn_fwd_static": (_i, [_vp] * 8 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp]),
     "sid_attn_plan": (_i, [_i] * 8 + [_c.POINTER(_c.c_int)]),
     "sid_plain_attn_workspace_bytes": (_sz, [_i] * 6),
     "sid_plain_attn_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_f] + [_i] * 5 + [_vp, _sz, _vp]),

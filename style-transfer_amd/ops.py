@@ -54,8 +54,10 @@ def _need_cuda(*ts):
 
 
 def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, gamma, T, scale,
-                       heads, q_self_coef=0.5, compute="bf16", out=None, flags=0):
-    """x_q (B,N,H*d); q_cnt,k*,v* (B*H,N,d); mask_signed (B,N) or (N,) float32 -> (B,N,H*d)."""
+                       heads, q_self_coef=0.5, compute="bf16", out=None, flags=0, static_scratch=False):
+    """x_q (B,N,H*d); q_cnt,k*,v* (B*H,N,d); mask_signed (B,N) or (N,) float32 -> (B,N,H*d).
+    static_scratch=True goes through sid_injected_attn_fwd_static (pass `out` to keep the call free of
+    allocations altogether); calls on one GPU must then not overlap."""
     L = _lib.load()
     B, N, C = x_q.shape
     H = heads
@@ -73,6 +75,15 @@ def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, ga
     cc = _compute_code(compute)
     if out is None:
         out = torch.empty((B, N, C), dtype=x_q.dtype, device=dev)
+    if static_scratch:
+        # the entry point that allocates nothing: scratch is the library's static device array
+        with torch.cuda.device(dev):
+            _lib.check(L.sid_injected_attn_fwd_static(
+                x_q.data_ptr(), q_cnt.data_ptr(), k1.data_ptr(), v1.data_ptr(), k2.data_ptr(), v2.data_ptr(),
+                k_cnt.data_ptr(), v_cnt.data_ptr(), mask_signed.data_ptr(), out.data_ptr(),
+                B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale), dt, cc, int(flags),
+                _stream(dev)))
+        return out
     nbytes = L.sid_injected_attn_workspace_bytes(B, H, N, d, cc)
     if nbytes == 0:
         raise _lib.SidError(-22, L.sid_last_error().decode())
