@@ -196,6 +196,13 @@ def plain_attention(q, k, v, scale, T=1.0, dtype=F32):
     return merge_heads(np.einsum("hij,hjd->hid", _softmax(sim), v))
 
 
+def plain_attention_rows(rows, q, k, v, scale, T=1.0, dtype=np.float64):
+    """plain_attention restricted to the query rows `rows` (all keys); (len(rows), H*d)."""
+    q, k, v = (np.asarray(a, dtype=dtype) for a in (np.asarray(q)[:, np.asarray(rows)], k, v))
+    sim = np.einsum("hid,hjd->hij", q, k) * dtype(T) * dtype(scale)
+    return merge_heads(np.einsum("hij,hjd->hid", _softmax(sim), v))
+
+
 def blend_query(xq, q_cnt, gamma, q_self_coef=0.5):
     """q = q_cnt*gamma + split_heads(to_q(x))*0.5; the 0.5 is a literal in the reference
     (ldm/modules/attention.py:381)."""

@@ -99,3 +99,16 @@ def param_init(name, shape):
     if name.endswith("weight"):
         return (1.0 + normal(seed, shape, sigma=0.1)).astype(np.float32)
     return normal(seed, shape, sigma=0.05)
+
+
+def stub_eps(x, t, c, injected_features=None):
+    """Closed-form stand-in for a UNet noise prediction (torch tensors in and out): a fixed linear map
+    of the latent plus terms in the timestep, the conditioning and the step's feature dict, so sampler
+    loops can be compared between implementations without network weights."""
+    import torch
+    e = 0.6 * torch.roll(x, 1, -1) - 0.25 * x + 0.05 * torch.sin(t.to(x.dtype) / 100.0).reshape(-1, 1, 1, 1)
+    if c is not None:
+        e = e + 0.1 * c.to(x.dtype).mean()
+    if injected_features is not None:
+        e = e + float(injected_features["shift"])
+    return e

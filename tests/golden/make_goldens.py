@@ -171,6 +171,23 @@ def attn_cases():
                       sigma_v=1.0, mask="disc", seed=100 + cid)); cid += 1
     cases.append(dict(id=cid, branch="injected", heads=2, N=100, d=64, gamma=0.3, T=0.5, sigma_qk=1.0,
                       sigma_v=1.0, mask="half", seed=100 + cid)); cid += 1
+    # single-block attention at the 64x64 level (input blocks 1, 2 of the UNet): 4096 keys, head_dim 40
+    cases.append(dict(id=cid, branch="tplain", heads=8, N=4096, d=40, gamma=0.75, T=1.5, sigma_qk=1.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid)); cid += 1
+    cases.append(dict(id=cid, branch="plain", heads=8, N=4096, d=40, gamma=None, T=None, sigma_qk=1.0,
+                      sigma_v=1.0, mask="none", seed=100 + cid)); cid += 1
+    cases.append(dict(id=cid, branch="tplain", heads=8, N=4096, d=40, gamma=0.5, T=1.0, sigma_qk=2.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid)); cid += 1
+    cases.append(dict(id=cid, branch="styleid_nomask", heads=8, N=4096, d=40, gamma=0.75, T=1.5, sigma_qk=1.5,
+                      sigma_v=1.0, mask="none", seed=100 + cid)); cid += 1
+    # feature-like magnitudes (q, k three times unit scale: raw q.k reaches the hundreds, so does the
+    # mask bias) with EVERY fractional (mask-edge) row of the real mask among the stored rows
+    cases.append(dict(id=cid, branch="injected", heads=8, N=1024, d=80, gamma=0.75, T=1.5, sigma_qk=3.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid, all_frac=True)); cid += 1
+    cases.append(dict(id=cid, branch="injected", heads=8, N=4096, d=40, gamma=0.5, T=1.5, sigma_qk=3.0,
+                      sigma_v=1.0, mask="content_flower_mask", seed=100 + cid, all_frac=True)); cid += 1
+    cases.append(dict(id=cid, branch="injected", heads=8, N=4096, d=40, gamma=0.75, T=1.5, sigma_qk=3.0,
+                      sigma_v=1.0, mask="content_car_mask", seed=100 + cid, all_frac=True)); cid += 1
     return cases
 
 
@@ -192,7 +209,7 @@ def gen_attention():
                     side = int(round(np.sqrt(N)))
                     m = ref_mask_downsample(mask_for(c["mask"]), side, side, 1.0)
                     frac = np.nonzero(np.abs(m) != 1.0)[0]
-                    rows = np.unique(np.concatenate([rows, frac[:8]]))
+                    rows = np.unique(np.concatenate([rows, frac if c.get("all_frac") else frac[:8]]))
             c["rows"] = [int(r) for r in rows]
             arrays[f"out_rows/{c['id']}"] = out[rows].astype(np.float32)
             arrays[f"colsum/{c['id']}"] = out.astype(np.float64).sum(axis=0)
@@ -376,8 +393,204 @@ def gen_unet():
           "diff", np.abs(out["injected"] - out["plain"]).max())
 
 
+def build_ref_unet():
+    """The reference's UNetModel, half width, with name-seeded weights (see gen_unet)."""
+    import types
+    stub = types.ModuleType("omegaconf")
+    stub.listconfig = types.ModuleType("omegaconf.listconfig")
+    stub.listconfig.ListConfig = list
+    sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = stub, stub.listconfig
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    model = UNetModel(image_size=32, use_spatial_transformer=True, use_checkpoint=False, legacy=False, **UNET_CFG).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(synth.param_init(name, p.shape)))
+    return model
+
+
+def last_resblocks(model):
+    """(block_id, module) of the last ResBlock of output blocks 6..11, found the way
+    high_frequency_final.py:53-58 and generate_pkl_only.py:153-158 find it."""
+    found = []
+    for block_id in range(6, 12):
+        for module in reversed(model.output_blocks[block_id]):
+            if module.__class__.__name__.endswith("ResBlock"):
+                found.append((block_id, module))
+                break
+    return found
+
+
+HF_PATCH = dict(residual_steps=[21, 381, 401], unet_t=481, ratios=[0.5, 0.25])
+
+
+def gen_hf_patch():
+    """The high-frequency injection end to end on the reference's own code: content residuals captured
+    per timestep exactly as generate_pkl_only.py:144-178 does (out_skip / out_h / out_merged of the last
+    ResBlock of output blocks 6-11 after a forward on the content latent), the decoder patched by the
+    reference's patch_decoder_resblocks_h_and_cnt_hf with the reference's schedule, `ri_timestep` set
+    on those ResBlocks as hf_run.py:256-270 does, then an injected forward.  Pinned: checksums of the
+    residuals, and the UNet output for ri_timestep = 21 (scheduled, stored: filter applied), 401
+    (stored, not scheduled) and 1 (scheduled, not stored): the last two must equal the unpatched
+    output."""
+    import ast
+    import types
+    model = build_ref_unet()
+    attns = [m for m in model.modules() if isinstance(m, ref_attn.CrossAttention)]
+    out = {}
+    ctx = torch.from_numpy(unet_inputs("cnt")[1])
+    # content residuals at three "timesteps" (the content latent is re-seeded per step so they differ)
+    residuals_all = {}
+    with tempfile.TemporaryDirectory() as td:
+        for m in attns:
+            m.cnt_name = os.path.join(td, "nomask.jpg")
+        for t_int in HF_PATCH["residual_steps"]:
+            x = torch.from_numpy(synth.normal(8100 + t_int, (1, 4, 16, 16)))
+            with torch.no_grad():
+                model(x, torch.tensor([t_int]), ctx)
+            residuals_all[t_int] = {}
+            for block_id, module in last_resblocks(model):
+                residuals_all[t_int][f"output_block_{block_id}_cnt_skip"] = module.out_skip.detach().cpu()
+                residuals_all[t_int][f"output_block_{block_id}_cnt_h"] = module.out_h.detach().cpu()
+                residuals_all[t_int][f"output_block_{block_id}_residual"] = module.out_merged.detach().cpu()
+            for k, v in residuals_all[t_int].items():
+                out[f"res/{t_int}/{k}"] = np.array([v.double().sum().item(), (v.double() ** 2).sum().item()])
+        # merged injected features, as gen_unet builds them
+        feats = {}
+        for tag in ("cnt", "char", "back"):
+            for m in attns:
+                m.gen_pkl = True
+            x, c2 = unet_inputs(tag)
+            with torch.no_grad():
+                model(torch.from_numpy(x), torch.tensor([HF_PATCH["unet_t"]]), torch.from_numpy(c2))
+            f = {"config": {"T": 1.5}, "z_enc": torch.from_numpy(x)}
+            for bi in range(6, 12):
+                a = model.output_blocks[bi][1].transformer_blocks[0].attn1
+                for nm in "qkv":
+                    f[f"output_block_{bi}_self_attn_{nm}"] = getattr(a, nm).clone()
+            for m in attns:
+                m.gen_pkl = False
+            feats[tag] = f
+        src = open(os.path.join(REF, "run_ori.py")).read()
+        fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "feat_merge_2sty"][0]
+        ns = {}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "run_ori.py", "exec"), ns)
+        opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+        merged = ns["feat_merge_2sty"](opt, [feats["cnt"]] * 50, [feats["char"]] * 50, [feats["back"]] * 50, start_step=50)[0]
+        np.save(os.path.join(td, "img_mask.npy"), np.load(os.path.join(MASK_DIR, MASK_NAMES[0] + ".npy")))
+        for m in attns:
+            m.cnt_name = os.path.join(td, "img.jpg")
+        x, c2 = unet_inputs("cur")
+        xt, ct, tt = torch.from_numpy(x), torch.from_numpy(c2), torch.tensor([HF_PATCH["unet_t"]])
+        with torch.no_grad():
+            out["unpatched"] = model(xt, tt, ct, injected_features=merged).numpy()
+        sched50 = make_ddim_timesteps("uniform", 50, 1000, verbose=False)
+        schedule = ref_hf.make_content_injection_schedule(sched50, alpha=0.4)
+        import contextlib
+        import io
+        for ratio in HF_PATCH["ratios"]:
+            fresh = build_ref_unet()
+            for m in fresh.modules():
+                if isinstance(m, ref_attn.CrossAttention):
+                    m.cnt_name = os.path.join(td, "img.jpg")
+            ref_hf.patch_decoder_resblocks_h_and_cnt_hf(fresh, schedule, residuals_all, ratio=ratio)
+            for ri in (21, 401, 1):
+                for _, module in last_resblocks(fresh):          # hf_run.py:263-270
+                    module.ri_timestep = int(ri)
+                with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                    out[f"patched/r{ratio}/ri{ri}"] = fresh(xt, tt, ct, injected_features=merged).numpy()
+            assert np.array_equal(out[f"patched/r{ratio}/ri401"], out["unpatched"])
+            assert np.array_equal(out[f"patched/r{ratio}/ri1"], out["unpatched"])
+            assert np.abs(out[f"patched/r{ratio}/ri21"] - out["unpatched"]).max() > 1e-2
+    np.savez_compressed(os.path.join(HERE, "hf_patch.npz"), **out)
+    with open(os.path.join(HERE, "hf_patch_case.json"), "w") as f:
+        json.dump(dict(HF_PATCH, schedule=[int(t) for t in schedule]), f)
+    print("hf_patch: diff patched vs unpatched", np.abs(out["patched/r0.5/ri21"] - out["unpatched"]).max(),
+          "r0.25 vs r0.5", np.abs(out["patched/r0.5/ri21"] - out["patched/r0.25/ri21"]).max())
+
+
+def gen_ddim():
+    """The reference DDIMSampler (ldm/models/diffusion/ddim.py) driven by a stub model that carries the
+    SD-v1 noise schedule (ddpm.py:117-146 with linear_start 0.00085, linear_end 0.012 of
+    v1-inference.yaml) and a closed-form noise prediction (synth.stub_eps).  Pinned: the ddim_* tables
+    for 50 and 5 steps at eta 0 and 0.5, the encode_ddim trajectory (every callback latent) and the
+    sample() result with and without the skipped first step.  The only harness change: register_buffer
+    keeps tensors where they are (the reference moves them to "cuda", ddim.py:19-23)."""
+    import contextlib
+    import io
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+
+    class Stub:
+        def __init__(self):
+            betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.0120, cosine_s=8e-3)
+            ac = np.cumprod(1.0 - betas, axis=0)
+            f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+            self.betas, self.alphas_cumprod = f32(betas), f32(ac)
+            self.alphas_cumprod_prev = f32(np.append(1.0, ac[:-1]))
+            self.sqrt_alphas_cumprod = f32(np.sqrt(ac))
+            self.sqrt_one_minus_alphas_cumprod = f32(np.sqrt(1.0 - ac))
+            self.num_timesteps = 1000
+            self.device = torch.device("cpu")
+            self.calls = []
+
+        def apply_model(self, x, t, c, injected_features=None):
+            self.calls.append((int(t[0]), None if injected_features is None else injected_features["tag"]))
+            return synth.stub_eps(x, t, c, injected_features)
+
+    class Sampler(DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    out, meta = {}, {}
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    for steps in (50, 5):
+        for eta in (0.0, 0.5):
+            s = Sampler(Stub())
+            with quiet:
+                s.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=False)
+            for nm in ("ddim_sigmas", "ddim_alphas", "ddim_alphas_prev", "ddim_sqrt_one_minus_alphas"):
+                out[f"tab/{steps}/{eta}/{nm}"] = np.asarray(getattr(s, nm), dtype=np.float64)
+            out[f"tab/{steps}/{eta}/ddim_timesteps"] = np.asarray(s.ddim_timesteps)
+        x0 = torch.from_numpy(synth.normal(9100 + steps, (1, 4, 8, 8)))
+        uc = torch.from_numpy(synth.normal(9200, (1, 77, 16), sigma=0.5))
+        stub = Stub()
+        s = Sampler(stub)
+        with quiet:
+            s.make_schedule(ddim_num_steps=steps, ddim_eta=0.0, verbose=False)
+        traj = []
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            z, pred = s.encode_ddim(x0.clone(), num_steps=steps, unconditional_conditioning=uc, end_step=981,
+                                    callback_ddim_timesteps=steps,
+                                    img_callback=lambda p, xt, t: traj.append((int(t), xt.clone(), p.clone())))
+        meta[f"encode_t/{steps}"] = [t for t, _, _ in traj]
+        meta[f"encode_calls/{steps}"] = [c[0] for c in stub.calls]
+        out[f"encode/{steps}/xt"] = torch.stack([a for _, a, _ in traj]).numpy()
+        out[f"encode/{steps}/pred_x0"] = torch.stack([b for _, _, b in traj]).numpy()
+        out[f"encode/{steps}/final"] = z.numpy()
+        feats = [{"tag": i, "shift": 0.01 * i} for i in range(steps)]
+        for start_step in (steps - 1, 9999):
+            stub = Stub()
+            s = Sampler(stub)
+            seen = []
+            with quiet, contextlib.redirect_stderr(io.StringIO()):
+                samples, _ = s.sample(S=steps, batch_size=1, shape=[4, 8, 8], verbose=False, unconditional_conditioning=uc,
+                                      eta=0.0, x_T=z.clone(), injected_features=feats, start_step=start_step,
+                                      callback=lambda i: seen.append(int(i)))
+            out[f"sample/{steps}/{start_step}"] = samples.numpy()
+            meta[f"sample_calls/{steps}/{start_step}"] = [list(c) for c in stub.calls]
+            meta[f"sample_callback_i/{steps}/{start_step}"] = seen
+    np.savez_compressed(os.path.join(HERE, "ddim.npz"), **out)
+    with open(os.path.join(HERE, "ddim_case.json"), "w") as f:
+        json.dump(meta, f)
+    print("ddim: tables", sum(k.startswith("tab/") for k in out), "trajectories", sum(k.startswith("encode/") for k in out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain", "unet"]
+    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain", "unet", "hf_patch", "ddim"]
+    if "ddim" in which:
+        gen_ddim()
+    if "hf_patch" in which:
+        gen_hf_patch()
     if "unet" in which:
         gen_unet()
     if "adain" in which:

@@ -33,7 +33,10 @@ def check_rows(t, out, b, rows, d, tol):
     c = lambda x: x.cpu().numpy()
     ref = orc.injected_attention_rows(rows, c(t["xq"][b]), c(t["q_cnt"][sl]), c(t["k1"][sl]), c(t["v1"][sl]), c(t["k2"][sl]),
                                       c(t["v2"][sl]), c(t["k_cnt"][sl]), c(t["v_cnt"][sl]), c(t["mask"][b]), 0.5, 1.5, d ** -0.5)
-    assert rel_err(c(out[b])[rows], ref) < tol, b
+    got = c(out[b])[rows]
+    assert rel_err(got, ref) < tol, b
+    return got, ref, (c(t["xq"][b]), c(t["q_cnt"][sl]), c(t["k1"][sl]), c(t["v1"][sl]), c(t["k2"][sl]), c(t["v2"][sl]),
+                      c(t["k_cnt"][sl]), c(t["v_cnt"][sl]), c(t["mask"][b]), 0.5, 1.5, d ** -0.5)
 
 
 @pytest.mark.parametrize("N,d,sigma", [(4096, 40, 1.0), (1024, 80, 1.0), (256, 160, 1.0), (64, 160, 1.0), (4096, 40, 2.0)])
@@ -45,8 +48,16 @@ def test_batch16_levels(N, d, sigma):
     out = run(t, d, "bf16")
     assert torch.isfinite(out).all()
     rows = (synth.hash_u64(6001, 12) % np.uint64(N)).astype(np.int64)
+    import bf16_model
     for b in (0, 7, 15):
-        check_rows(t, out, b, rows, d, 2e-2 if sigma == 1.0 else 4e-2)
+        # 2e-2 holds at both scales; at sigma 2 the error (1.2e-2 at most, against 5e-3 at sigma 1) is the
+        # rounding of the bf16 operands, which the operand-rounding model reproduces to 4e-3
+        got, ref, args = check_rows(t, out, b, rows, d, 2e-2)
+        model = bf16_model.injected_attention_rows(rows, *args)
+        rr = np.abs(got - ref).max(1) / np.abs(ref).max(1)
+        print("N=%d sigma=%.0f image %d: max-normalised %.2e, per-row max %.2e, vs operand model %.2e"
+              % (N, sigma, b, rel_err(got, ref), rr.max(), rel_err(got, model)))
+        assert rel_err(got, model) < 4e-3
     ones = dict(t, v1=torch.ones_like(t["v1"]), v2=torch.ones_like(t["v2"]), v_cnt=torch.ones_like(t["v_cnt"]))
     assert (run(ones, d, "bf16") - 1).abs().max().item() < 1e-5
 

@@ -101,6 +101,14 @@ def test_content_logits_that_outgrow_the_first_stage(N, compute):
         # kernel does (the f32-grade mode above is exact on the same rows)
         err = np.abs(out[rows] - ref).max(axis=1) / np.abs(ref).max()
         assert (err < TOL[compute]).mean() > 0.97 and err.max() < 5 * TOL[compute]
+        # ... and the operand-rounding model (exact arithmetic on bf16-rounded operands) lands on the
+        # kernel's result in those rows too
+        import bf16_model
+        model = bf16_model.injected_attention_rows(rows, t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"],
+                                                   t["k_cnt"], t["v_cnt"], m, gamma, T, scale)
+        merr = np.abs(out[rows] - model).max(axis=1) / np.abs(ref).max()
+        print("outlier rows: vs reference max %.2e, vs operand model max %.2e" % (err.max(), merr.max()))
+        assert merr.max() < TOL[compute]
 
 
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])

@@ -15,6 +15,26 @@ from style_transfer_amd import ops, synth
 pytestmark = pytest.mark.gpu
 
 TOL = {"bf16": 2e-2, "fp32": 1e-3}
+# bf16 operands: the error of a logit grows with |q||k|, and a peaked softmax turns it into an output
+# error of the same relative size.  Measured (tools/err_dist.py) and reproduced by the operand-rounding
+# model (oracle/bf16_model.py): 5e-3 at unit-scale q, k; 1.2e-2 at twice, 2.5-2.9e-2 at three times that
+# scale.  The 2e-2 bar therefore holds up to sigma 2; at sigma 3 the bound below applies and the kernel
+# must still sit on the model, i.e. add nothing to what bf16 operands cost any implementation.
+BF16_BOUND_SIGMA3 = 3.5e-2
+MODEL_TOL = 4e-3
+
+
+def bar(case, compute):
+    if compute == "bf16" and case["sigma_qk"] > 2.0:
+        return BF16_BOUND_SIGMA3
+    return TOL[compute]
+
+
+def row_rel_err(a, b):
+    """Per-row relative error max_c|a-b| / max_c|b|: stricter than the tensor-wide norm of `rel_err`
+    on rows whose entries are small."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-30)
 
 
 def dev():
@@ -85,9 +105,15 @@ def test_injected_attention_vs_reference_golden(case, compute):
     rows = np.array(case["rows"])
     want = gold[f"out_rows/{case['id']}"]
     assert np.isfinite(out).all()
-    assert rel_err(out[rows], want) < TOL[compute]
+    tol = bar(case, compute)
+    assert rel_err(out[rows], want) < tol
+    # per-row relative error, the stricter reading of "relative": twice the tensor-wide bar at most
+    rr = row_rel_err(out[rows], want)
+    print("case %d %s: max-normalised %.2e, per-row p50 %.2e max %.2e" % (case["id"], compute, rel_err(out[rows], want),
+                                                                          np.median(rr), rr.max()))
+    assert rr.max() < 2 * tol
     # every row enters the column sums: an error outside the sampled rows shows here
-    check_sums(out, gold, case, TOL[compute])
+    check_sums(out, gold, case, tol)
     # one row of every 32-query tile (all heads) against the float64 oracle: no tile goes unchecked
     N = case["N"]
     t = case_inputs(case)
@@ -97,7 +123,13 @@ def test_injected_attention_vs_reference_golden(case, compute):
     probe = np.minimum(tiles + (synth.hash_u64(case["seed"] + 7, len(tiles)) % np.uint64(32)).astype(np.int64), N - 1)
     ref = orc.injected_attention_rows(probe, t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"],
                                       t["v_cnt"], m, case["gamma"], case["T"], case["d"] ** -0.5)
-    assert rel_err(out[probe], ref) < TOL[compute]
+    assert rel_err(out[probe], ref) < tol
+    if compute == "bf16":
+        # the whole difference from the reference is operand rounding: the kernel sits on the model
+        import bf16_model
+        model = bf16_model.injected_attention_rows(rows, t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"],
+                                                   t["k_cnt"], t["v_cnt"], m, case["gamma"], case["T"], case["d"] ** -0.5)
+        assert rel_err(out[rows], model) < MODEL_TOL
 
 
 PLAIN = [c for c in attention_cases() if c["branch"] in ("tplain", "plain", "styleid_nomask", "genpkl")
@@ -122,6 +154,43 @@ def test_plain_attention_vs_reference_golden(case, compute):
     rows = np.array(case["rows"])
     assert rel_err(out[rows], gold[f"out_rows/{case['id']}"]) < TOL[compute]
     check_sums(out, gold, case, TOL[compute])
+
+
+BIG_PLAIN = [c for c in PLAIN if c["N"] == 4096]
+
+
+@pytest.mark.parametrize("flags", [0, ops.FLAG_THROUGHPUT], ids=["default", "throughput"])
+@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", BIG_PLAIN, ids=lambda c: f"{c['id']}-{c['branch']}-T{c['T']}")
+def test_plain_attention_4096_every_query_tile(case, compute, flags):
+    """Single-block attention at Nq = Nk = 4096, head_dim 40 (input blocks 1, 2 of the UNet; 98 calls per
+    image): both decompositions (the default one that fills an idle GPU and the least-work one of
+    concurrent callers) against the reference's golden rows, the checksums over all rows, and one
+    float64 oracle row in every 32-query tile."""
+    gold = attention_golden()
+    t = case_inputs(case)
+    H, d, N = case["heads"], case["d"], case["N"]
+    scale = d ** -0.5
+    if case["branch"] == "styleid_nomask":
+        qh = orc.blend_query(t["xq"][0], t["q_cnt"], case["gamma"])
+        kh, vh = t["k1"], t["v1"]
+        T = case["T"]
+        out = ops.plain_attention(g(qh), g(kh), g(vh), T * scale, H, "bhnd", "bhnd", compute, flags=flags)
+    else:
+        qh = kh = vh = orc.split_heads(t["xq"][0], H)
+        T = case["T"] if case["branch"] == "tplain" else 1.0
+        x = g(t["xq"])
+        out = ops.plain_attention(x, x, x, T * scale, H, "bnhd", "bnhd", compute, flags=flags)
+    out = out[0].cpu().numpy()
+    assert np.isfinite(out).all()
+    rows = np.array(case["rows"])
+    assert rel_err(out[rows], gold[f"out_rows/{case['id']}"]) < TOL[compute]
+    check_sums(out, gold, case, TOL[compute])
+    tiles = np.arange(0, N, 32)
+    probe = np.minimum(tiles + (synth.hash_u64(case["seed"] + 11, len(tiles)) % np.uint64(32)).astype(np.int64), N - 1)
+    ref = orc.plain_attention_rows(probe, qh, kh, vh, scale, T)
+    assert rel_err(out[probe], ref) < TOL[compute]
+    assert row_rel_err(out[probe], ref).max() < 2 * TOL[compute]
 
 
 def test_hf_filter_vs_reference_golden():
