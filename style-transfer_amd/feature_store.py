@@ -100,6 +100,43 @@ def validate_layout(feats):
                 raise ValueError("step %d: q/k/v of %s disagree in shape: %s" % (i, blk, sorted(sh)))
 
 
+RESIDUAL_SUFFIXES = ("_cnt_h", "_cnt_skip", "_residual")
+
+
+def validate_residuals(residuals_all):
+    """Raise ValueError unless `residuals_all` has the layout of `{base}_residuals_all.pkl`
+    (generate_pkl_only.py:144-178, 310-316): `{int timestep: {"output_block_{i}_cnt_h" |
+    "..._cnt_skip" | "..._residual": (1,C,H,W) tensor}}`."""
+    if not isinstance(residuals_all, dict):
+        raise ValueError("a residuals file holds a dict keyed by timestep, got %s" % type(residuals_all).__name__)
+    for t, entry in residuals_all.items():
+        if not isinstance(t, int) or not isinstance(entry, dict):
+            raise ValueError("residuals: key %r must be an int timestep mapping to a dict" % (t,))
+        for k, v in entry.items():
+            if not (k.startswith("output_block_") and k.endswith(RESIDUAL_SUFFIXES)):
+                raise ValueError("residuals[%d]: unexpected key %r" % (t, k))
+            if not torch.is_tensor(v) or v.dim() != 4:
+                raise ValueError("residuals[%d][%r] must be a (B,C,H,W) tensor" % (t, k))
+
+
+def save_residuals_file(path, residuals_all):
+    """Write `{base}_residuals_all.pkl` as the reference does (plain pickle of the dict of CPU tensors,
+    generate_pkl_only.py:310-316)."""
+    validate_residuals(residuals_all)
+    with open(path, "wb") as f:
+        pickle.dump({int(t): {k: v.detach().cpu() for k, v in e.items()} for t, e in residuals_all.items()}, f)
+
+
+def load_residuals_file(path, device="cuda"):
+    """Read `{base}_residuals_all.pkl` with the allow-list unpickler; tensors land on `device` (the
+    reference keeps them on the CPU and moves one per ResBlock call, high_frequency_final.py:76)."""
+    with open(path, "rb") as f:
+        residuals = _SafeUnpickler(f, torch.device(device)).load()
+    validate_residuals(residuals)
+    dev = torch.device(device)
+    return {t: {k: v.to(dev).contiguous() for k, v in e.items()} for t, e in residuals.items()}
+
+
 class FeatureStore:
     """The three feature lists of one (content, character style, background style) triple, resident
     on one device, and the merged per-step dicts the UNet consumes (run_ori.py:36-75, 235)."""

@@ -70,3 +70,15 @@ def patch_decoder_resblocks_h_and_cnt_hf(unet, schedule, residuals_all, ratio=0.
 
             module._forward = types.MethodType(patched, module)
             break
+
+
+def unpatch_decoder_resblocks(unet):
+    """Undo patch_decoder_resblocks_h_and_cnt_hf (the reference has no such call: it patches once per
+    process; a sweep over images with and without residual files needs it)."""
+    for block in unet.output_blocks:
+        for module in block:
+            inner = getattr(module, "_unpatched_forward", None)
+            if inner is not None:
+                module._forward = inner
+                module._unpatched_forward = None
+                module.ri_timestep = None

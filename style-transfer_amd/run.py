@@ -117,17 +117,20 @@ def stylise(opt, model, sampler, triple, uc, device):
     res_path = os.path.join(opt.precomputed, base(cnt_path) + "_residuals_all.pkl")
     callback = None
     if os.path.isfile(res_path):                                       # high-frequency injection, --ratio
-        import pickle
-        with open(res_path, "rb") as f:
-            residuals = fs._SafeUnpickler(f, torch.device(device)).load()
+        from .sampler import last_resblocks
+        residuals = fs.load_residuals_file(res_path, device)
         schedule = set(int(t) for t in make_content_injection_schedule(sampler.ddim_timesteps, alpha=0.4))
         patch_decoder_resblocks_h_and_cnt_hf(model, schedule, residuals, ratio=opt.ratio)
+        for _, m in last_resblocks(model):
+            m.ri_timestep = None                                       # no stale timestep from the previous image
 
-        def callback(i):
+        def callback(i):                                               # hf_run.py:256-270
             t = int(sampler.ddim_timesteps[i])
-            for m in model.modules():
-                if hasattr(m, "block_id"):
-                    m.ri_timestep = t
+            for _, m in last_resblocks(model):
+                m.ri_timestep = t
+    else:
+        from .high_frequency import unpatch_decoder_resblocks
+        unpatch_decoder_resblocks(model)                               # a patch left by the previous image
     return sampler.sample(x_T, uc, injected_features=feats, start_step=opt.start_step, callback=callback)
 
 

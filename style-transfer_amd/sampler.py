@@ -79,11 +79,43 @@ class DDIMSampler:
         return img, pred_x0
 
 
-def extract_features(unet, x0, unconditional_conditioning, num_steps=50, blocks=range(6, 12), T=1.5):
+def last_resblocks(unet, blocks=range(6, 12)):
+    """(block_id, module) of the last ResBlock of each output block in `blocks`: the ones the
+    high-frequency injection reads and patches (high_frequency_final.py:53-58,
+    generate_pkl_only.py:153-158)."""
+    found = []
+    for block_id in blocks:
+        if block_id >= len(unet.output_blocks):
+            break
+        for module in reversed(unet.output_blocks[block_id]):
+            if module.__class__.__name__.endswith("ResBlock"):
+                found.append((block_id, module))
+                break
+    return found
+
+
+def capture_residuals(unet, blocks=range(6, 12)):
+    """The content residuals of the UNet evaluation that has just run, in the layout of one timestep of
+    `{base}_residuals_all.pkl` (generate_pkl_only.py:153-178): `output_block_{i}_cnt_skip` = out_skip,
+    `..._cnt_h` = out_h, `..._residual` = their sum, of the last ResBlock of output blocks 6-11, as CPU
+    tensors."""
+    entry = {}
+    for block_id, module in last_resblocks(unet, blocks):
+        if module.out_skip is None or module.out_h is None:
+            continue
+        entry["output_block_%d_cnt_skip" % block_id] = module.out_skip.detach().cpu()
+        entry["output_block_%d_cnt_h" % block_id] = module.out_h.detach().cpu()
+        entry["output_block_%d_residual" % block_id] = (module.out_skip + module.out_h).detach().cpu()
+    return entry
+
+
+def extract_features(unet, x0, unconditional_conditioning, num_steps=50, blocks=range(6, 12), T=1.5, residuals=None):
     """The producer of a `precomputed_feats_k` list (generate_pkl_only.py:90-142): DDIM inversion with the
     attention modules in feature-extraction mode; after the step at timestep t the q, k, v of the
     self-attention of output blocks 6-11 and the latent go to entry i = (981 - t) / 20, so entry 0
-    holds the fully inverted latent."""
+    holds the fully inverted latent.  With `residuals` a dict, every step also records the content
+    residuals of its UNet evaluation under `residuals[int(t)]` (the content image's
+    `residual_injection_callback`, generate_pkl_only.py:144-178): what `{base}_residuals_all.pkl` holds."""
     sampler = DDIMSampler(unet)
     sampler.make_schedule(num_steps, 0.0)
     index_of = {int(t): i for i, t in enumerate(np.flip(sampler.ddim_timesteps))}
@@ -99,6 +131,8 @@ def extract_features(unet, x0, unconditional_conditioning, num_steps=50, blocks=
             for nm in "qkv":
                 e["output_block_%d_self_attn_%s" % (b, nm)] = getattr(a, nm).detach().clone()
         e["z_enc"] = xt.detach().clone()
+        if residuals is not None:
+            residuals.setdefault(int(t), {}).update(capture_residuals(unet, blocks))
 
     try:
         sampler.encode_ddim(x0, unconditional_conditioning, num_steps, img_callback=record)
