@@ -94,6 +94,37 @@ int sid_injected_attn_fwd(const void* x_q, const void* q_cnt,
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Pre-packed K/V: the feature store's side of the injected attention.
+ * The key/value tensors of a call come from the precomputed feature files (run_ori.py:168-222 loads
+ * them, run_ori.py:36-75 re-keys them) and never change between images, so their conversion to the
+ * kernels' operand layout ("fragment image": bf16 MFMA operand order, head_dim padded, V transposed
+ * with a ones column) can happen once, when a feature file is loaded, instead of in every call.
+ * No counterpart in the reference, which keeps the tensors in fp32 and re-reads them per call.
+ *
+ *   sid_kv_image_bytes   size of the image of one (k, v) pair of shape (B*H, N, d)
+ *   sid_pack_kv          k, v (B*H, N, d) in `dtype` -> image (256-byte aligned, caller-owned)
+ *   sid_injected_attn_fwd_packed
+ *                        sid_injected_attn_fwd with the three (k, v) pairs given as images made with the
+ *                        same B, H, N, d and compute; x_q, q_cnt and out are tensors of `dtype` as before.
+ *                        Same results bit for bit; the workspace is smaller
+ *                        (sid_injected_attn_packed_workspace_bytes).
+ */
+size_t sid_kv_image_bytes(int B, int H, int N, int d, int compute);
+
+int sid_pack_kv(const void* k, const void* v, void* image, size_t image_bytes,
+                int B, int H, int N, int d, int dtype, int compute, void* stream);
+
+size_t sid_injected_attn_packed_workspace_bytes(int B, int H, int N, int d, int compute);
+
+int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt,
+                                 const void* kv1_image, const void* kv2_image, const void* kv_cnt_image,
+                                 const float* mask_signed, void* out,
+                                 int B, int H, int N, int d,
+                                 float gamma, float q_self_coef, float T, float scale,
+                                 int dtype, int compute, int flags,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * sid_injected_attn_fwd for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments and results as sid_injected_attn_fwd without the workspace pair: the scratch is a

@@ -180,13 +180,37 @@ __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// (DKS, DVB) of the kernel instance that serves head_dim d: the smallest instantiated pair that holds
+// ceil(d / 16) k-steps and ceil((d + 1) / 32) dv blocks.  A larger pair only adds zero padding (the
+// ones column sits in the last dv block of the pair, wherever that is).
 bool supported_dims(int d, int* DKS, int* DVB) {
     const int dks = (d + 15) / 16, dvb = (d + 1 + 31) / 32;
-    // instantiated (DKS, DVB) pairs
     static const int table[][2] = {{2, 1}, {2, 2}, {3, 2}, {4, 2}, {4, 3}, {5, 3}, {6, 4}, {8, 5}, {10, 6}};
     for (auto& t : table)
-        if (t[0] == dks && t[1] == dvb) { *DKS = dks; *DVB = dvb; return true; }
+        if (t[0] >= dks && t[1] >= dvb) { *DKS = t[0]; *DVB = t[1]; return true; }
     return false;
+}
+
+// head dims whose two spare padding columns d, d+1 of the last k-step carry the softmax reference
+// (the kShifted instances): the instance must not be a rounded-up one
+bool has_shift_cols(int d, int DKS) { return d % 16 == 8 && d <= 72 && DKS == (d + 15) / 16; }
+
+// Measurement and test overrides from the environment, validated on every read (values outside the
+// ranges below are ignored): SID_TUNE_NW in {1,2,4,8}, SID_TUNE_KS in [1,8], SID_TUNE_W in [1,kMaxRuns],
+// SID_TUNE_NO_SMALL=1.  Not for production use: the environment must not change while calls run.
+struct Tune { int nw = 0, ks = 0, w = 0; bool no_small = false; };
+Tune tune() {
+    Tune r;
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+    const int nw = num("SID_TUNE_NW");
+    if (nw == 1 || nw == 2 || nw == 4 || nw == 8) r.nw = nw;
+    const int ks = num("SID_TUNE_KS");
+    if (ks >= 1 && ks <= 8) r.ks = ks;
+    const int w = num("SID_TUNE_W");
+    if (w >= 1 && w <= kMaxRuns) r.w = w;
+    const char* e = getenv("SID_TUNE_NO_SMALL");
+    r.no_small = e && e[0] == '1';
+    return r;
 }
 
 // Decomposition of one call: waves per workgroup and key splits -- sized so the grid covers the
@@ -194,7 +218,7 @@ bool supported_dims(int d, int* DKS, int* DVB) {
 // SID_TUNE_NW / SID_TUNE_KS override the choice (measurement only).
 int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool throughput, Geometry* g) {
     if (!supported_dims(d, &g->DKS, &g->DVB))
-        return sid::fail(SID_ENOSYS, "head_dim %d has no kernel instance (supported: 17-48, 49-64, 65-80, 81-96, 113-128, 145-160)", d);
+        return sid::fail(SID_ENOSYS, "head_dim %d has no kernel instance (supported: 1-160)", d);
     g->KVS = stage_tiles(g->DKS, g->DVB, x3);
     g->QT = query_tiles(g->DKS, g->DVB, x3);
     g->NQT = (Nq + 31) / 32;
@@ -210,7 +234,7 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     // starving the younger one (measured: 2-4 % at N >= 4096, a loss at N = 1024)
     int nw = qwaves >= 64 ? 8 : 4;
     while (nw > 1 && qwaves < nw) nw >>= 1;
-    if (const char* e = getenv("SID_TUNE_NW")) nw = atoi(e);
+    if (tune().nw) nw = tune().nw;
     g->NW = nw;
     g->nQG = (qwaves + nw - 1) / nw;
     // Runs per (head, query group).  The nblk * stages key stages of a head are cut into W equal runs
@@ -221,6 +245,7 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     // Concurrent callers (throughput) take one run per block: the fewest partials, no rounding loss
     // to recover because other kernels fill the machine.
     const int T = nblk * stages;
+    SID_CHECK_ARG(T <= 65535, "%d key stages per head exceed the 65535 a run boundary can hold", T);
     auto slots_per_block = [&](int G_) {
         int most = 1;
         for (int b = 0; b < nblk; ++b) most = std::max(most, ((b + 1) * stages - 1) / G_ - (b * stages) / G_ + 1);
@@ -238,8 +263,8 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
             if (cost < best - 1e-9) { best = cost; W = w; }
         }
     }
-    if (const char* e = getenv("SID_TUNE_KS")) W = nblk * atoi(e);       // the same number of runs per block
-    if (const char* e = getenv("SID_TUNE_W")) W = atoi(e);
+    if (tune().ks) W = nblk * tune().ks;       // the same number of runs per block
+    if (tune().w) W = tune().w;
     W = std::max(1, std::min(std::min(W, T), kMaxRuns));
     g->SPB = stages;
     g->W = W;
@@ -291,15 +316,18 @@ struct Workspace {
     size_t bytes;
 };
 
-void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, void* base, Workspace* w) {
+// `with_kv` false: the K/V fragment images live outside the workspace (pre-packed by sid_pack_kv)
+void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, void* base, Workspace* w, bool with_kv = true) {
     size_t off = 0;
     auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += sid::align_up(bytes, 256); return p; };
     const int parts = x3 ? 2 : 1;
     for (int i = 0; i < 2; ++i) for (int p = 0; p < 2; ++p) w->q[i][p] = nullptr;
     for (int i = 0; i < kBlocks; ++i) for (int p = 0; p < 2; ++p) { w->k[i][p] = nullptr; w->v[i][p] = nullptr; }
     for (int i = 0; i < nq; ++i) for (int p = 0; p < parts; ++p) w->q[i][p] = (u32x4*)take(g.q_units * 16);
-    for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->k[i][p] = (u32x4*)take(g.k_units * 16);
-    for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->v[i][p] = (u32x4*)take(g.v_units * 16);
+    if (with_kv) {
+        for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->k[i][p] = (u32x4*)take(g.k_units * 16);
+        for (int i = 0; i < nblk; ++i) for (int p = 0; p < parts; ++p) w->v[i][p] = (u32x4*)take(g.v_units * 16);
+    }
     const int np = nblk * g.KS;                     // rows = B*H*Nq
     w->opart = w->stats = nullptr;
     if (np > 1) {
@@ -307,6 +335,20 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, 
         w->stats = (float*)take((size_t)np * rows * 16);
     }
     w->bytes = off;
+}
+
+// A pre-packed K/V pair (sid_pack_kv): [K hi | K lo | V hi | V lo], every part 256-byte aligned, the lo
+// parts only in the f32-grade mode.  The layout depends on (B*H, N, d, compute) only.
+struct KvImage { u32x4* k[2]; u32x4* v[2]; size_t bytes; };
+void carve_kv(const Geometry& g, bool x3, const void* base, KvImage* im) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { u32x4* p = base ? (u32x4*)((char*)base + off) : nullptr; off += sid::align_up(bytes, 256); return p; };
+    im->k[1] = im->v[1] = nullptr;
+    im->k[0] = take(g.k_units * 16);
+    if (x3) im->k[1] = take(g.k_units * 16);
+    im->v[0] = take(g.v_units * 16);
+    if (x3) im->v[1] = take(g.v_units * 16);
+    im->bytes = off;
 }
 
 // element strides {batch, head, token} of a layout
@@ -324,8 +366,7 @@ void set_strides(PackJob& j, int layout, int H, int N, int d, bool second) {
 // Short key sequences take the single-launch kernel; SID_TUNE_NO_SMALL=1 forces the general path
 // (measurement and tests only).
 bool use_small_path(int Nk, int d) {
-    const char* e = getenv("SID_TUNE_NO_SMALL");
-    return small_attn_supported(Nk, d) && !(e && e[0] == '1');
+    return small_attn_supported(Nk, d) && !tune().no_small;
 }
 
 int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream) {
@@ -437,11 +478,17 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
                        const float* mask_signed, void* out, int B, int H, int N, int d,
                        float gamma, float q_self_coef, float T, float scale, int dtype,
                        int compute, int flags, void* workspace, size_t workspace_bytes,
-                       bool static_ws, hipStream_t stream) {
+                       bool static_ws, hipStream_t stream, const void* const* kv_images = nullptr) {
     const Stages stg(flags);
     int rc = check_common(B, H, N, N, d, dtype, compute);
     if (rc != SID_OK) return rc;
-    SID_CHECK_ARG(x_q && q_cnt && k1 && v1 && k2 && v2 && k_cnt && v_cnt && mask_signed && out, "NULL tensor pointer");
+    if (kv_images) {
+        SID_CHECK_ARG(x_q && q_cnt && kv_images[0] && kv_images[1] && kv_images[2] && mask_signed && out, "NULL tensor pointer");
+        for (int b = 0; b < kBlocks; ++b)
+            SID_CHECK_ARG(((uintptr_t)kv_images[b] & 255) == 0, "K/V images must be 256-byte aligned");
+    } else {
+        SID_CHECK_ARG(x_q && q_cnt && k1 && v1 && k2 && v2 && k_cnt && v_cnt && mask_signed && out, "NULL tensor pointer");
+    }
     SID_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace must be non-NULL and 256-byte aligned");
     SID_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
     SID_CHECK_ARG(std::isfinite(gamma) && std::isfinite(q_self_coef) && std::isfinite(T) && std::isfinite(scale),
@@ -451,7 +498,14 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
     rc = make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
     if (rc != SID_OK) return rc;
     Workspace w;
-    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w);
+    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w, kv_images == nullptr);
+    if (kv_images) {
+        for (int b = 0; b < kBlocks; ++b) {
+            KvImage im;
+            carve_kv(g, x3, kv_images[b], &im);
+            for (int p = 0; p < 2; ++p) { w.k[b][p] = im.k[p]; w.v[b][p] = im.v[p]; }
+        }
+    }
     if (w.bytes > workspace_bytes) {
         if (static_ws)
             return sid::fail(SID_ENOMEM, "B=%d H=%d N=%d d=%d needs %zu bytes of scratch; the static buffer of "
@@ -462,12 +516,12 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
 
     // logit scales in the log2 domain; applied to the query images by the pack kernel
     const float c2s = clamp_scale(T * scale * LOG2E), c2c = clamp_scale(scale * LOG2E);
-    const bool shift_cols = d % 16 == 8 && d <= 72;      // head dims with a shifted-reference instance
+    const bool shift_cols = has_shift_cols(d, g.DKS);    // head dims with a shifted-reference instance
 
     // ---- pack
     if (stg.pack) {
         PackParams pp = {};
-        pp.njobs = 8; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+        pp.njobs = kv_images ? 2 : 8; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
         long long frags[kMaxJobs];
         auto rowjob = [&](int i, const void* src, u32x4* dst, u32x4* dst_lo, int NT, size_t units) {
             PackJob& j = pp.job[i];
@@ -484,7 +538,7 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
         pp.job[1].post = c2c;
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};
-        for (int b = 0; b < kBlocks; ++b) {
+        for (int b = 0; b < kBlocks && !kv_images; ++b) {
             rowjob(2 + b, ks[b], w.k[b][0], w.k[b][1], g.NKT, g.k_units);
             pp.job[2 + b].ones_at = shift_cols ? d : -1;
             rowjob(5 + b, vs[b], w.v[b][0], w.v[b][1], g.NKT, g.v_units);
@@ -531,6 +585,71 @@ extern "C" int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt, 
     return injected_attn_impl(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, out, B, H, N, d, gamma,
                               q_self_coef, T, scale, dtype, compute, flags, ws, (size_t)SID_STATIC_SCRATCH_BYTES, true,
                               (hipStream_t)stream);
+}
+
+extern "C" size_t sid_kv_image_bytes(int B, int H, int N, int d, int compute) {
+    Geometry g;
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    if (make_geometry(B, H, N, N, d, kBlocks, x3, false, &g) != SID_OK) return 0;
+    KvImage im;
+    carve_kv(g, x3, nullptr, &im);
+    return im.bytes;
+}
+
+extern "C" int sid_pack_kv(const void* k, const void* v, void* image, size_t image_bytes, int B, int H, int N, int d,
+                           int dtype, int compute, void* stream) {
+    int rc = check_common(B, H, N, N, d, dtype, compute);
+    if (rc != SID_OK) return rc;
+    SID_CHECK_ARG(k && v && image, "NULL tensor pointer");
+    SID_CHECK_ARG(((uintptr_t)image & 255) == 0, "the image must be 256-byte aligned");
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    Geometry g;
+    rc = make_geometry(B, H, N, N, d, kBlocks, x3, false, &g);
+    if (rc != SID_OK) return rc;
+    KvImage im;
+    carve_kv(g, x3, image, &im);
+    if (im.bytes > image_bytes)
+        return sid::fail(SID_ENOMEM, "image of %zu bytes is smaller than the %zu required", image_bytes, im.bytes);
+    PackParams pp = {};
+    pp.njobs = 2; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+    long long frags[kMaxJobs];
+    for (int i = 0; i < 2; ++i) {
+        PackJob& j = pp.job[i];
+        j = PackJob{};
+        j.src = i == 0 ? k : v; j.dst = i == 0 ? im.k[0] : im.v[0]; j.dst_lo = i == 0 ? im.k[1] : im.v[1];
+        j.kind = i; j.N = N; j.NT = g.NKT; j.post = 1.f;
+        j.ones_at = (i == 0 && has_shift_cols(d, g.DKS)) ? d : -1;
+        set_strides(j, SID_LAYOUT_BHND, H, N, d, false);
+        frags[i] = (long long)(i == 0 ? g.k_units : g.v_units);
+    }
+    return launch_pack(pp, frags, (hipStream_t)stream);
+}
+
+extern "C" size_t sid_injected_attn_packed_workspace_bytes(int B, int H, int N, int d, int compute) {
+    Geometry g;
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    size_t bytes = 0;
+    for (int thr = 0; thr < 2; ++thr) {
+        if (make_geometry(B, H, N, N, d, kBlocks, x3, thr != 0, &g) != SID_OK) return 0;
+        Workspace w;
+        carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w, false);
+        bytes = std::max(bytes, w.bytes);
+    }
+    return bytes;
+}
+
+extern "C" int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt, const void* kv1_image,
+                                            const void* kv2_image, const void* kv_cnt_image,
+                                            const float* mask_signed, void* out, int B, int H, int N, int d,
+                                            float gamma, float q_self_coef, float T, float scale, int dtype,
+                                            int compute, int flags, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    const void* images[kBlocks] = {kv1_image, kv2_image, kv_cnt_image};
+    return injected_attn_impl(x_q, q_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mask_signed, out, B, H, N, d,
+                              gamma, q_self_coef, T, scale, dtype, compute, flags, workspace, workspace_bytes, false,
+                              (hipStream_t)stream, images);
 }
 
 extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]) {
@@ -611,13 +730,13 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
         job(0, q, w.q[0][0], w.q[0][1], 0, Nq, g.NQT, g.q_units, q_layout);
         pp.job[0].post = c2p;
         job(1, k, w.k[0][0], w.k[0][1], 0, Nk, g.NKT, g.k_units, kv_layout);
-        pp.job[1].ones_at = (d % 16 == 8 && d <= 72) ? d : -1;
+        pp.job[1].ones_at = has_shift_cols(d, g.DKS) ? d : -1;
         job(2, v, w.v[0][0], w.v[0][1], 1, Nk, g.NKT, g.v_units, kv_layout);
         rc = launch_pack(pp, frags, stream);
         if (rc != SID_OK) return rc;
     }
     FlashParams fp = {};
-    fp.shift_cols = d % 16 == 8 && d <= 72;
+    fp.shift_cols = has_shift_cols(d, g.DKS);
     fp.q[0] = w.q[0][0]; fp.q_lo[0] = w.q[0][1];
     fp.k[0] = w.k[0][0]; fp.k_lo[0] = w.k[0][1];
     fp.v[0] = w.v[0][0]; fp.v_lo[0] = w.v[0][1];

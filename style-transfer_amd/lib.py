@@ -25,6 +25,10 @@ SIGNATURES = {
     "sid_injected_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sid_injected_attn_fwd": (_i, [_vp] * 8 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
     "sid_injected_attn_fwd_static": (_i, [_vp] * 8 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp]),
+    "sid_kv_image_bytes": (_sz, [_i] * 5),
+    "sid_pack_kv": (_i, [_vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
+    "sid_injected_attn_packed_workspace_bytes": (_sz, [_i] * 5),
+    "sid_injected_attn_fwd_packed": (_i, [_vp] * 5 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
     "sid_attn_plan": (_i, [_i] * 8 + [_c.POINTER(_c.c_int)]),
     "sid_plain_attn_workspace_bytes": (_sz, [_i] * 6),
     "sid_plain_attn_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_f] + [_i] * 5 + [_vp, _sz, _vp]),

@@ -30,12 +30,22 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_retired = []        # superseded workspaces stay alive: a captured HIP graph may hold their address
+
+
 def _workspace(device, nbytes):
     """One growing scratch buffer per (device, stream): calls on one stream run in order, so
-    they can share it; allocation happens here, never inside the library."""
+    they can share it; allocation happens here, never inside the library.  A HIP graph captured on
+    the stream bakes the buffer's address in, so the buffer must not grow during capture (warm up
+    eagerly with the largest shape first) and a buffer that is outgrown later is kept, not freed."""
     key = (device.index, _stream(device))
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("libsid workspace of %d bytes would have to be allocated during graph capture: run the "
+                               "call sequence once eagerly on this stream first" % nbytes)
+        if ws is not None:
+            _retired.append(ws)
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
@@ -98,6 +108,72 @@ def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, ga
 
 
 FLAG_THROUGHPUT = 2      # SID_FLAG_THROUGHPUT: the caller keeps the GPU busy with other streams
+
+
+class PackedKV:
+    """The key/value pair of one feature-list entry in the kernels' operand layout (sid_pack_kv): what a
+    feature store keeps in HBM instead of the two (B*H, N, d) tensors.  Stands in for BOTH tensors in
+    the injected-attention call (pass the same object as k and v)."""
+
+    def __init__(self, image, B, H, N, d, compute):
+        self.image, self.B, self.H, self.N, self.d, self.compute = image, B, H, N, d, compute
+
+    @property
+    def device(self):
+        return self.image.device
+
+    def nbytes(self):
+        return self.image.numel()
+
+
+def pack_kv(k, v, heads, compute="bf16"):
+    """k, v (B*H, N, d) float32 / bfloat16 -> PackedKV (one launch on the current stream)."""
+    L = _lib.load()
+    dev = _need_cuda(k, v)
+    if k.shape != v.shape or k.dtype != v.dtype or k.dim() != 3 or k.shape[0] % heads:
+        raise ValueError("k and v must be two (B*H, N, d) tensors of one dtype")
+    BH, N, d = k.shape
+    B = BH // heads
+    cc = _compute_code(compute)
+    nbytes = L.sid_kv_image_bytes(B, heads, N, d, cc)
+    if nbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    image = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_pack_kv(k.data_ptr(), v.data_ptr(), image.data_ptr(), nbytes, B, heads, N, d, _dtype_code(k), cc,
+                                 _stream(dev)))
+    return PackedKV(image, B, heads, N, d, cc)
+
+
+def injected_attention_packed(x_q, q_cnt, kv1, kv2, kv_cnt, mask_signed, gamma, T, scale, heads, q_self_coef=0.5,
+                              out=None, flags=0):
+    """injected_attention with the three key/value pairs pre-packed (PackedKV); same results."""
+    L = _lib.load()
+    B, N, C = x_q.shape
+    H = heads
+    d = C // H
+    dev = _need_cuda(x_q, q_cnt, mask_signed, kv1.image, kv2.image, kv_cnt.image)
+    if tuple(q_cnt.shape) != (B * H, N, d) or q_cnt.dtype != x_q.dtype:
+        raise ValueError("q_cnt must be (B*H, N, d) = %s of x_q's dtype" % ((B * H, N, d),))
+    cc = kv1.compute
+    for kv in (kv1, kv2, kv_cnt):
+        if (kv.B, kv.H, kv.N, kv.d, kv.compute) != (B, H, N, d, cc):
+            raise ValueError("packed K/V was made for (B,H,N,d,compute) = %s, the call has %s"
+                             % ((kv.B, kv.H, kv.N, kv.d, kv.compute), (B, H, N, d, cc)))
+    if mask_signed.dtype != torch.float32 or mask_signed.numel() != B * N:
+        raise ValueError("mask_signed must be float32 with B*N elements")
+    if out is None:
+        out = torch.empty((B, N, C), dtype=x_q.dtype, device=dev)
+    nbytes = L.sid_injected_attn_packed_workspace_bytes(B, H, N, d, cc)
+    if nbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_injected_attn_fwd_packed(
+            x_q.data_ptr(), q_cnt.data_ptr(), kv1.image.data_ptr(), kv2.image.data_ptr(), kv_cnt.image.data_ptr(),
+            mask_signed.data_ptr(), out.data_ptr(), B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale),
+            _dtype_code(x_q), cc, int(flags), ws.data_ptr(), ws.numel(), _stream(dev)))
+    return out
 
 
 def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="bf16", out=None, flags=0):

@@ -157,3 +157,19 @@ def test_attention_plan_of_the_headline_shapes():
     out = (ctypes.c_int * 40)()
     assert lib.load().sid_attn_plan(2, 1, 8, 64, 64, 40, 0, 0, out) != 0
     assert lib.load().sid_attn_plan(3, 1, 8, 64, 32, 40, 0, 0, out) != 0
+
+
+def test_every_head_dim_up_to_160_has_a_kernel_and_huge_key_counts_are_refused():
+    from style_transfer_amd import lib
+    L = lib.load()
+    plan = (ctypes.c_int * 40)()
+    for d in range(1, 161):
+        for blocks in (1, 3):
+            assert L.sid_attn_plan(blocks, 1, 8, 1024, 1024, d, 0, 0, plan) == 0, (d, blocks)
+            assert plan[0] >= 1
+    assert L.sid_attn_plan(3, 1, 8, 1024, 1024, 161, 0, 0, plan) == -22
+    # 3 blocks x ceil(N / 64) stages must fit the 16-bit run boundaries
+    assert L.sid_attn_plan(3, 1, 1, 1500000, 1500000, 40, 0, 0, plan) == -22
+    assert b"stages" in L.sid_last_error()
+    assert L.sid_kv_image_bytes(1, 8, 4096, 40, 0) == 8 * 4096 * (48 + 64) * 2
+    assert L.sid_injected_attn_packed_workspace_bytes(1, 8, 4096, 40, 0) < L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, 0)

@@ -31,6 +31,25 @@ def timed(flags):
     ev1.record(); ev1.synchronize()
     return ev0.elapsed_time(ev1) / reps
 tp, tf, tm = timed(0x10), timed(0x20), timed(0x40)
+kv = [ops.pack_kv(f[1 + 2 * i], f[2 + 2 * i], H, compute) for i in range(3)]
+def packed(flags=0):
+    return ops.injected_attention_packed(xq, f[0], kv[0], kv[1], kv[2], m, 0.5, 1.5, d ** -0.5, H, flags=flags)
+for _ in range(reps):
+    packed()
+ev0.record()
+for _ in range(reps):
+    packed()
+ev1.record(); ev1.synchronize()
+tpk = ev0.elapsed_time(ev1) / reps
+for _ in range(3):
+    packed(0x10)
+ev0.record()
+for _ in range(reps):
+    packed(0x10)
+ev1.record(); ev1.synchronize()
+tqp = ev0.elapsed_time(ev1) / reps
 fl = 12.0 * B * H * N * N * d
 print("N=%d d=%d B=%d: call %.1f us (%.1f TF/s) | pack %.1f us | merge %.1f us | flash %.1f us (%.1f TF/s = %.1f%% of 2.5 PF)" % (
     N, d, B, t * 1e3, fl / (t * 1e-3) / 1e12, tp * 1e3, tm * 1e3, tf * 1e3, fl / (tf * 1e-3) / 1e12, fl / (tf * 1e-3) / 2.5e15 * 100))
+print("   pre-packed K/V: call %.1f us (%.1f TF/s = %.1f%% of 2.5 PF) | query pack %.1f us" % (
+    tpk * 1e3, fl / (tpk * 1e-3) / 1e12, fl / (tpk * 1e-3) / 2.5e15 * 100, tqp * 1e3))
