@@ -3,140 +3,300 @@
 
 A step is the hot path of ONE stylised image (50 DDIM steps = 49 UNet evaluations): per
 evaluation 6 injected three-block attentions (3 x N=4096,d=40 and 3 x N=1024,d=80), the 10
-non-injected self-attentions of the UNet (7 plain, 3 temperature-scaled), and, on the 20
-scheduled evaluations, the fused high-frequency filter of the 6 decoder ResBlocks
-(3 x (640,32,32), 3 x (320,64,64)).  The convolutions, GroupNorms, cross-attention, VAE and
-sampler arithmetic of the UNet are NOT part of the path and are not run.  Inputs are synthetic
-(seeded normal), already resident in HBM; every evaluation reads its own feature tensors, as
-the precomputed feature lists do.
+non-injected self-attentions of the UNet (7 plain, 3 temperature-scaled), and, on the 19
+evaluations the reference's schedule reaches, the fused high-frequency filter of the 6 decoder
+ResBlocks (3 x (640,32,32), 3 x (320,64,64)).  The convolutions, GroupNorms, cross-attention, VAE
+and sampler arithmetic of the UNet are NOT part of the path and are not run in `value` (the `e2e`
+record times the whole UNet loop separately).  Inputs are synthetic (seeded normal), already
+resident in HBM; every evaluation reads its own feature, query and latent tensors, as the
+precomputed feature lists and the evolving latent do.  The feature store keeps the key/value pairs
+in the kernels' operand layout (FeatureStore.pack / sid_pack_kv, done when a feature file is
+loaded, outside the timed region); `--store tensors` keeps them as fp32 tensors instead.
 
     python bench.py --gpus N --steps K --warmup W
 
-prints one JSON line on rank 0.  For N > 1 launch with torch.distributed.run; every rank
-stylises its own images (the path shards over images, no data-path collective) and rank 0
-gathers the output latents once at the end over RCCL.
+prints one JSON line on rank 0.  With N > 1 and no WORLD_SIZE in the environment the command starts
+its own N ranks (one process per GPU) before anything touches a GPU; under torch.distributed.run it
+uses the ranks it is given.  Every rank stylises its own images (the path shards over images, no
+data-path collective) and rank 0 gathers the output latents once at the end over RCCL.
 
 Images are independent, so each GPU keeps `--in-flight` (default 3) of them going at once, one HIP
-stream each, and the ~2300 kernel launches of an image are captured once as a HIP graph and
-replayed: the half-empty last wave of workgroups of one image's attention and its small
-latency-bound kernels overlap with another image's work.  `--in-flight 1 --no-graph` is the plain
-one-image-at-a-time launch sequence.
+stream and one workload each, and the ~2300 kernel launches of an image are captured once as a HIP
+graph and replayed.  `--in-flight 1 --no-graph` is the plain one-image-at-a-time launch sequence.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from style_transfer_amd import lib as sid_lib  # noqa: E402
-from style_transfer_amd import ops  # noqa: E402
-from style_transfer_amd import sharding  # noqa: E402
-
 HEADS = 8
 GAMMA, TEMP, RATIO = 0.5, 1.5, 0.5
 EVALS = 49
-HF_EVALS = 20                     # int(0.4 * 50) scheduled timesteps
+# The reference's callback hands the ResBlocks ddim_timesteps[i] of loop position i after step i
+# (hf_run.py:256-270), so position i + 1 filters when that timestep is among the first 40 % of the
+# ascending list: positions 2..20 of 0..49, i.e. evaluations 1..19 of the 49 (position 0 is skipped).
+HF_FIRST, HF_EVALS = 1, 19
 INJECTED = [(1024, 80)] * 3 + [(4096, 40)] * 3            # output blocks 6-8, 9-11
 PLAIN = [(4096, 40, 1.0)] * 2 + [(1024, 80, 1.0)] * 2 + [(256, 160, 1.0)] * 2 + [(64, 160, 1.0)] + \
         [(256, 160, TEMP)] * 3                            # input 1,2,4,5,7,8; middle; output 3,4,5 (T)
 HF_MAPS = [(640, 32)] * 3 + [(320, 64)] * 3
-MFMA_PEAK = 2.5e15                # dense bf16 MFMA, FLOP/s (MI355X spec)
+MFMA_PEAK = 2.5e15                # dense bf16 MFMA, FLOP/s (MI355X)
 HBM_PEAK = 8.0e12
 
 
-def make_image_workload(dev, gen, dtype, batch=1):
-    """All tensors the hot path of `batch` images (processed together, one problem per image) reads,
-    resident on `dev`."""
-    B = batch
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the query / latent tensors")
+    ap.add_argument("--store", default="packed", choices=["packed", "tensors"],
+                    help="feature store layout of the key/value pairs: the kernels' operand layout, or tensors")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (host UNet around the path)")
+    ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
+    ap.add_argument("--rank-probe", action="store_true", help=argparse.SUPPRESS)   # launcher test: print the rank environment and exit
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start `n` fresh processes of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    the way torch.distributed.run sets them), relay rank 0's output and return the worst exit code.  Called
+    before this process has made any GPU call: nothing here touches HIP."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    codes = [p.wait() for p in procs]
+    return max((abs(c) for c in codes), default=0)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rank_probe:
+        print(json.dumps({"rank": rank, "local_rank": local, "world": world, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT")}), flush=True)
+        return
+    run_rank(args, world, rank, local)
+
+
+# ----------------------------------------------------------------------------------------------
+# everything below runs inside one rank
+# ----------------------------------------------------------------------------------------------
+def make_image_workload(dev, gen, dtype, store, compute):
+    """All tensors the hot path of one image reads, resident on `dev`: per evaluation its own query
+    projection, feature tensors (or packed key/value pairs), plain-attention inputs and content maps."""
+    import torch
+    from style_transfer_amd import ops
+
     def rn(*shape):
         return torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dtype)
 
-    w = {"inj": [], "plain": [], "hf": [], "batch": B}
-    w["z"] = [[rn(1, 4, 64, 64).float() for _ in range(3)] for _ in range(B)]   # inverted latents: content / char / back
+    w = {"inj": [], "plain": [], "hf": [], "store": store}
+    w["z"] = [rn(1, 4, 64, 64).float() for _ in range(3)]          # inverted latents: content / char / back
+    yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
+    disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
+    w["mask512"] = disc
     for (N, d) in INJECTED:
-        layer = {"N": N, "d": d, "xq": rn(B, N, HEADS * d), "feats": []}
-        for _ in range(EVALS):
-            layer["feats"].append([rn(B * HEADS, N, d) for _ in range(7)])   # q_cnt k1 v1 k2 v2 k_cnt v_cnt
         side = int(N ** 0.5)
-        yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
-        disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
-        layer["mask"] = ops.mask_downsample(disc, side, side, 1.0).repeat(B).reshape(B, -1).contiguous()
-        w["mask512"] = disc
+        layer = {"N": N, "d": d, "xq": [rn(1, N, HEADS * d) for _ in range(EVALS)], "feats": [],
+                 "mask": ops.mask_downsample(disc, side, side, 1.0).reshape(1, -1).contiguous()}
+        for _ in range(EVALS):
+            q_cnt = rn(HEADS, N, d)
+            pairs = [(rn(HEADS, N, d), rn(HEADS, N, d)) for _ in range(3)]       # char, back, content
+            if store == "packed":
+                layer["feats"].append((q_cnt, [ops.pack_kv(k, v, HEADS, compute) for k, v in pairs]))
+            else:
+                layer["feats"].append((q_cnt, pairs))
         w["inj"].append(layer)
     for (N, d, T) in PLAIN:
-        w["plain"].append({"N": N, "d": d, "T": T, "q": rn(B, N, HEADS * d), "k": rn(B, N, HEADS * d),
-                           "v": rn(B, N, HEADS * d)})
+        w["plain"].append({"N": N, "d": d, "T": T,
+                           "qkv": [tuple(rn(1, N, HEADS * d) for _ in range(3)) for _ in range(EVALS)]})
     for (C, S) in HF_MAPS:
-        w["hf"].append({"h_cnt": [rn(B, C, S, S) for _ in range(HF_EVALS)], "skip": rn(B, C, S, S), "h": rn(B, C, S, S)})
+        w["hf"].append({"h_cnt": [rn(1, C, S, S) for _ in range(HF_EVALS)], "skip": rn(1, C, S, S), "h": rn(1, C, S, S)})
+    torch.cuda.synchronize()
     return w
+
+
+def injected_call(layer, e, compute, flags=0):
+    from style_transfer_amd import ops
+    q_cnt, kv = layer["feats"][e]
+    scale = layer["d"] ** -0.5
+    if isinstance(kv[0], ops.PackedKV):
+        return ops.injected_attention_packed(layer["xq"][e], q_cnt, kv[0], kv[1], kv[2], layer["mask"], GAMMA, TEMP, scale,
+                                             HEADS, flags=flags)
+    return ops.injected_attention(layer["xq"][e], q_cnt, kv[0][0], kv[0][1], kv[1][0], kv[1][1], kv[2][0], kv[2][1],
+                                  layer["mask"], GAMMA, TEMP, scale, HEADS, compute=compute, flags=flags)
 
 
 def run_image(w, compute, flags=0):
     """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
+    from style_transfer_amd import ops
     outs = None
-    for z in w["z"]:
-        ops.masked_adain(z[0], z[1], z[2], w["mask512"])
+    ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
     for e in range(EVALS):
-        for p in w["plain"][:7]:
-            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
-        for p in w["plain"][7:]:
-            ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
-        hf_on = e >= EVALS - HF_EVALS          # the 20 smallest timesteps come last
+        for p in w["plain"]:
+            q, k, v = p["qkv"][e]
+            ops.plain_attention(q, k, v, p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
+        hf_on = HF_FIRST <= e < HF_FIRST + HF_EVALS
         for li, layer in enumerate(w["inj"]):
             if hf_on:
                 m = w["hf"][li]
-                ops.hf_filter(m["h_cnt"][e - (EVALS - HF_EVALS)], RATIO, skip=m["skip"], h=m["h"])
-            f = layer["feats"][e]
-            outs = ops.injected_attention(layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"],
-                                          GAMMA, TEMP, layer["d"] ** -0.5, HEADS, compute=compute, flags=flags)
+                ops.hf_filter(m["h_cnt"][e - HF_FIRST], RATIO, skip=m["skip"], h=m["h"])
+            outs = injected_call(layer, e, compute, flags)
     return outs
 
 
-def flash_kernel_time(w, compute, reps=300):
-    """Average duration of the dominant kernel (the flash stage at N=4096, d=40), HIP events on
-    the launch stream around `reps` back-to-back launches.  The same number of untimed launches runs
-    first: after an idle gap the chip takes tens of milliseconds to return to its working clock
-    (measured: 103 us per launch right after 2 s of idle, 84 us sustained)."""
-    layer = w["inj"][-1]
-    f = layer["feats"][0]
-    args = (layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"], GAMMA, TEMP, layer["d"] ** -0.5, HEADS)
-    ops.injected_attention(*args, compute=compute)                      # full call fills the workspace
+def events_per_call(fn, reps):
+    """Average duration of `fn()` from HIP events on the current stream around `reps` back-to-back calls,
+    after the same number of untimed ones (after an idle gap the chip needs tens of milliseconds to return
+    to its working clock)."""
+    import torch
     for _ in range(reps):
-        ops.injected_attention(*args, compute=compute, flags=0x20)      # flash stage only
+        fn()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
-        ops.injected_attention(*args, compute=compute, flags=0x20)
+        fn()
     ev1.record()
     ev1.synchronize()
     return ev0.elapsed_time(ev1) * 1e-3 / reps
 
 
+def kernel_records(w, compute):
+    """The dominant kernel and its call, alone on the GPU: the flash stage of the injected attention at
+    N=4096, d=40, B=1 (HIP events around back-to-back launches of that stage), the whole call as the feature
+    store serves it (query pack + flash + merge), and the fused high-frequency filter at (320,64,64)."""
+    from style_transfer_amd import ops
+    layer = w["inj"][-1]
+    injected_call(layer, 0, compute)                                   # a full call fills the workspace
+    t_flash = events_per_call(lambda: injected_call(layer, 0, compute, flags=0x20), 300)      # flash stage only
+    t_call = events_per_call(lambda: injected_call(layer, 0, compute), 300)
+    flops = 12.0 * 1 * HEADS * 4096 ** 2 * 40           # 3 QK^T + 3 PV blocks, d = 40 (no padding counted)
+    m = w["hf"][-1]
+    t_hf = events_per_call(lambda: ops.hf_filter(m["h_cnt"][0], RATIO, skip=m["skip"], h=m["h"]), 300)
+    hf_bytes = 16.0 * 320 * 64 * 64                     # three reads + one write of a (1,320,64,64) f32 map
+    roof = {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true> injected attention N=4096 d=40 H=8 B=1",
+            "achieved": flops / t_flash / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": flops / t_flash / MFMA_PEAK, "kernel_ms": t_flash * 1e3, "algorithmic_flop": flops,
+            "call_ms": t_call * 1e3, "call_frac": flops / t_call / MFMA_PEAK,
+            "call": "whole injected-attention call at B=1, key/value pairs %s" %
+                    ("pre-packed by the feature store: query pack + flash + merge" if w["store"] == "packed"
+                     else "packed per call: pack + flash + merge")}
+    roof.update(measured_traffic())
+    hf = {"bound": "hbm", "kernel": "sid_hf::hf2_kernel fused skip + h + HF(h_cnt), (1,320,64,64) f32", "kernel_ms": t_hf * 1e3,
+          "achieved": hf_bytes / t_hf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hf_bytes / t_hf / HBM_PEAK,
+          "algorithmic_bytes": hf_bytes}
+    return roof, hf
+
+
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
-    WRITE_SIZE, each in its own rocprofv3 run, corrected for gfx950), or None."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE,
+    each in its own rocprofv3 run, corrected for gfx950): counters cannot be read inside this run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flash_traffic.json")))
     if not files:
-        return None
+        return {"traffic": None}
     with open(files[-1]) as f:
-        return json.load(f).get("traffic_bytes")
+        return {"traffic": json.load(f).get("traffic_bytes"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
 
 
-def cpu_baseline(seconds_budget=20.0):
+def e2e_record(dev, compute, store):
+    """The whole stylisation loop of run_ori.py around the path, driver-timed: this package's host UNet
+    (SD-v1 topology and size, seeded random fp32 weights: no checkpoint exists offline) under DDIM, masked
+    AdaIN init, synthetic feature lists in the precomputed_feats_k layout, 49 evaluations per image."""
+    import tempfile
+    import types
+    import numpy as np
+    import torch
+    from style_transfer_amd import feature_store as fs, synth, unet as U
+    from style_transfer_amd.features import masked_adain_init
+    from style_transfer_amd.sampler import DDIMSampler
+    g = torch.Generator(device=dev)
+
+    def feature_list(seed):
+        g.manual_seed(seed)
+        out = []
+        for _ in range(50):
+            e = {"config": {"T": TEMP}, "z_enc": torch.randn(1, 4, 64, 64, device=dev, generator=g)}
+            for b in range(6, 12):
+                n, d = (1024, 80) if b < 9 else (4096, 40)
+                for t in "qkv":
+                    e["output_block_%d_self_attn_%s" % (b, t)] = torch.randn(8, n, d, device=dev, generator=g)
+            out.append(e)
+        return out
+
+    fstore = fs.FeatureStore(feature_list(1), feature_list(2), feature_list(3))
+    z = fstore.z_enc()
+    if store == "packed":
+        fstore.pack(HEADS, compute)
+    merged = fstore.merged(types.SimpleNamespace(gamma=GAMMA, T=TEMP), start_step=49)
+    mask = synth.disc_mask()
+    td = tempfile.mkdtemp()
+    np.save(os.path.join(td, "img_mask.npy"), mask)
+    torch.manual_seed(0)
+    model = U.UNetModel().eval().to(dev)
+    model.set_content_name(os.path.join(td, "img.jpg"))
+    for a in model.attention_modules():
+        a.compute = compute
+    s = DDIMSampler(model)
+    s.make_schedule(50, 0.0)
+    ctx = torch.randn(1, 77, 768, device=dev, generator=g)
+    mask_dev = torch.from_numpy(mask).to(dev)
+
+    def one():
+        x_T = masked_adain_init(z[0], z[1], z[2], mask_dev)
+        return s.sample(x_T, ctx, injected_features=merged, start_step=49)
+
+    one()                                # warm-up: the convolution library picks its kernels here
+    torch.cuda.synchronize()
+    images = 2
+    t0 = time.perf_counter()
+    for _ in range(images):
+        out = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / images
+    assert torch.isfinite(out).all()
+    return {"value": 1.0 / dt, "unit": "imgs/s", "s_per_image": dt, "images": images,
+            "what": "masked AdaIN init + 49 evaluations of the host UNet (SD-v1 size, random fp32 weights, stock "
+                    "PyTorch convolutions) with the HIP attention kernels, one image at a time, no graph; VAE and "
+                    "text encoder not run"}
+
+
+def cpu_baseline():
     """The C oracle (oracle/, a port of the reference arithmetic) timed on this host's cores on a
     bounded sample of query rows / feature maps of the same workload, scaled to one image."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import sid_oracle_c as oc
     rng = np.random.default_rng(0)
     per_image = 0.0
-    sample = []
+    sample, factors = [], {}
 
     def timed(fn):
         t0 = time.perf_counter()
@@ -151,42 +311,35 @@ def cpu_baseline(seconds_budget=20.0):
         oc.injected_attention_rows(0, 16, *a, m, GAMMA, TEMP, d ** -0.5)
         t = timed(lambda: oc.injected_attention_rows(0, rows, *a, m, GAMMA, TEMP, d ** -0.5))
         per_image += EVALS * count * t * N / rows
-        sample.append("injected N=%d d=%d: %d of %d rows" % (N, d, rows, N))
+        factors["injected_N%d" % N] = EVALS * count * N / rows
+        sample.append("injected N=%d d=%d: %d of %d rows of one call" % (N, d, rows, N))
     for (N, d, T) in sorted(set(PLAIN)):
         count = PLAIN.count((N, d, T))
         rows = min(N, 256)
         q, k, v = (rng.standard_normal((HEADS, N, d), dtype=np.float32) for _ in range(3))
         t = timed(lambda: oc.plain_attention_rows(0, rows, q, k, v, d ** -0.5, T))
         per_image += EVALS * count * t * N / rows
-    sample.append("plain self-attention: <=256 rows per shape")
+        factors["plain_N%d_T%g" % (N, T)] = EVALS * count * N / rows
+    sample.append("plain self-attention: <=256 rows of one call per shape")
     for (C, S) in sorted(set(HF_MAPS)):
         maps = 64
         x, s, h = (rng.standard_normal((1, maps, S, S), dtype=np.float32) for _ in range(3))
         t = timed(lambda: oc.hf_filter(x, RATIO, s, h))
         per_image += HF_EVALS * 3 * t * C / maps
-    sample.append("HF filter: 64 maps per shape")
+        factors["hf_%dx%d" % (S, S)] = HF_EVALS * 3 * C / maps
+    sample.append("HF filter: 64 maps of one call per shape")
     return {"value": 1.0 / per_image, "unit": "imgs/s", "cores": oc.threads(), "kind": "port",
-            "sample": "; ".join(sample) + "; scaled to 49 evaluations of one image"}
+            "sample": "; ".join(sample) + "; every timed sample is multiplied by the factor below to give its share of "
+                      "one image (49 evaluations)",
+            "extrapolation_factors": factors}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the feature tensors")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
-    args = ap.parse_args()
+def run_rank(args, world, rank, local):
+    import torch
+    from style_transfer_amd import lib as sid_lib
+    from style_transfer_amd import ops
+    from style_transfer_amd import sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the path has no CPU fallback)")
     sid_lib.load()
@@ -195,16 +348,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
     dtype = torch.float32 if args.io == "f32" else torch.bfloat16
-    w = make_image_workload(dev, gen, dtype)
 
-    # one lane per image in flight: a stream, and the image's launch sequence as a graph on it
+    # one lane per image in flight: a stream, its own workload, and the image's launch sequence as a graph
     n_lanes = max(1, args.in_flight)
     kflags = ops.FLAG_THROUGHPUT if n_lanes > 1 else 0      # images share the GPU: least-work decomposition
     lanes = []
     graph_error = None
-    for _ in range(n_lanes):
+    for li in range(n_lanes):
+        gen.manual_seed(1234 + 100 * rank + li)
+        w = make_image_workload(dev, gen, dtype, args.store, args.compute)
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
             run_image(w, args.compute, kflags)       # sizes this stream's workspace; first-use kernel attributes
@@ -218,7 +371,7 @@ def main():
             except Exception as e:                   # same kernels, launched one by one instead
                 graph, gout, graph_error = None, None, "%s: %s" % (type(e).__name__, e)
                 torch.cuda.synchronize()
-        lanes.append((st, graph, gout))
+        lanes.append((st, graph, gout, w))
     torch.cuda.synchronize()
 
     # the process group comes after graph capture, so no communicator thread touches the device meanwhile
@@ -230,6 +383,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
 
     def barrier():
         if dist is not None:
@@ -237,7 +391,7 @@ def main():
         torch.cuda.synchronize()
 
     def one_image(i):
-        st, graph, gout = lanes[i % n_lanes]
+        st, graph, gout, w = lanes[i % n_lanes]
         with torch.cuda.stream(st):
             if graph is not None:
                 graph.replay()
@@ -266,9 +420,9 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        t_flash = flash_kernel_time(w, args.compute)
-        flops = 12.0 * 1 * HEADS * 4096 ** 2 * 40           # 3 QK^T + 3 PV blocks, d = 40 (no padding counted)
-        achieved = flops / t_flash
+        roof, hf = kernel_records(lanes[0][3], args.compute)
+        store_bytes = sum(kv.nbytes() if isinstance(kv, ops.PackedKV) else kv[0].numel() * kv[0].element_size() * 2
+                          for layer in lanes[0][3]["inj"] for (_, kvs) in layer["feats"] for kv in kvs)
         line = {
             "metric": "stylized imgs/sec (512^2, 50 DDIM), injection hot path",
             "value": world * args.steps / elapsed,
@@ -284,18 +438,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: one content + char/back style pair, 512^2, gamma=0.5 T=1.5 ratio=0.5, "
                                    "49 UNet evaluations: 6 injected + 10 self attention calls each, fused HF filter "
-                                   "on 6 ResBlocks for 20 evaluations; hot path only (UNet convs/VAE not run)",
-                       "feature_storage": args.io, "images_per_rank": args.steps, "images_in_flight": n_lanes,
+                                   "on 6 ResBlocks for 19 evaluations; hot path only (UNet convs/VAE not run; see e2e)",
+                       "query_storage": args.io,
+                       "feature_store": ("key/value pairs pre-packed to bf16 operand layout at load time (%.2f GB per image)"
+                                         if args.store == "packed" else "fp32 tensors (%.2f GB per image)") % (store_bytes / 1e9),
+                       "images_per_rank": args.steps, "images_in_flight": n_lanes, "workloads_per_rank": n_lanes,
+                       "ranks": world if dist is None else dist.get_world_size(),
                        "launch": ("kernel by kernel" if args.no_graph else "one HIP graph per image") if graph_error is None
                        else "kernel by kernel (graph capture failed: %s)" % graph_error[:120],
                        "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true> injected attention N=4096 d=40 H=8 B=1",
-                         "achieved": achieved / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK, "traffic": measured_traffic(), "kernel_ms": t_flash * 1e3,
-                         "algorithmic_flop": flops},
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),   # N = 1 only
+            "roofline": roof,
+            "hf_filter": hf,
         }
-        print(json.dumps(line))
+        if world == 1:
+            del lanes[1:]
+            torch.cuda.empty_cache()
+            line["e2e"] = None if args.no_e2e else e2e_record(dev, args.compute, args.store)
+            line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        else:
+            line["e2e"] = None
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -110,10 +110,20 @@ class CrossAttention(nn.Module):
             side = int(math.sqrt(n))
             if side * side != n:
                 raise ValueError("token count %d is not a square grid" % n)
+            m = self.mask_cache.signed_mask(mask_path, side, side, x.device)
+            if isinstance(k_injected, ops.PackedKV):
+                # the feature store keeps the key/value pairs in the kernels' operand layout
+                # (FeatureStore.pack): one PackedKV stands for a block's k and v
+                q_cnt = self._as(q_injected, xq)
+                self.k, self.v = k_injected, v_injected
+                self._q, self._q_lazy = None, (lambda: q_cnt * gamma + self._split(xq) * (1. - 0.5))
+                out = ops.injected_attention_packed(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, cnt_k_injected, m,
+                                                    gamma, T, self.scale, self.heads, q_self_coef=0.5,
+                                                    flags=self.kernel_flags)
+                return self.to_out(out)
             feats = [q_injected, k_injected, v_injected, sty2_k_injected, sty2_v_injected, cnt_k_injected,
                      cnt_v_injected]
             feats = [self._as(f, xq) for f in feats]
-            m = self.mask_cache.signed_mask(mask_path, side, side, x.device)
             self.k, self.v = feats[1], feats[2]
             q_cnt = feats[0]
             self._q, self._q_lazy = None, (lambda: q_cnt * gamma + self._split(xq) * (1. - 0.5))
@@ -121,6 +131,10 @@ class CrossAttention(nn.Module):
             return self.to_out(out)
 
         # single-block attention
+        if isinstance(k_injected, ops.PackedKV):
+            raise TypeError("pre-packed key/value features serve the mask-based injected attention only; this call "
+                            "takes the single-block path (no mask file for %r): load the feature store unpacked"
+                            % (self.cnt_name,))
         if q_injected is None:
             q, q_layout = xq, "bnhd"
             self._q, self._q_lazy = None, (lambda: self._split(xq))

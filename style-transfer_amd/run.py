@@ -55,6 +55,7 @@ def build_parser():
     p.add_argument('--random_unet', action='store_true', help="seeded random weights instead of --ckpt (measurement)")
     p.add_argument('--compute', default='bf16', choices=['bf16', 'fp32'], help="attention kernel arithmetic")
     p.add_argument('--feature_dtype', default='float32', choices=['float32', 'bfloat16'], help="storage type of the feature store in HBM")
+    p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
 
@@ -107,6 +108,9 @@ def stylise(opt, model, sampler, triple, uc, device):
     model.set_content_name(cnt_path)                                   # run_ori.py:159-161
     dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
     store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype)
+    mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")
+    if not opt.unpacked_store and not opt.without_attn_injection and os.path.isfile(mask_file):
+        store.pack(compute=opt.compute)          # pre-packed K/V serve the mask-based injected attention
     cnt_z, char_z, back_z = store.z_enc()
     if opt.without_init_adain:
         x_T = cnt_z

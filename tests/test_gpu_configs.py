@@ -85,3 +85,25 @@ def test_hf_filter_128px_maps():
     assert rel_err(ops.hf_filter(f, 0.5).cpu().numpy(), f.cpu().numpy()) < 1e-5
     fused = ops.hf_filter(x, 0.5, skip=s, h=h)
     assert rel_err(fused.cpu().numpy(), (s + h + f).cpu().numpy()) < 1e-6
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver starts it (no WORLD_SIZE): two ranks, here both on the one
+    GPU of the box over gloo, one gather, one JSON line that says n_gpus 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SID_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-e2e"], env=env, capture_output=True,
+                       text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["value"] > 0
+    assert 0 < line["roofline"]["frac"] < 1 and 0 < line["roofline"]["call_frac"] <= line["roofline"]["frac"]
+    assert 0 < line["hf_filter"]["frac"] < 1

@@ -74,3 +74,20 @@ def run_world(n_items, world=2):
 def test_two_ranks_gloo_gather_even_and_ragged():
     assert "GATHER_OK 6 2" in run_world(6)[0]
     assert "GATHER_OK 5 2" in run_world(5)[0]      # rank 1 holds one item fewer: padded for the gather
+
+
+def test_bench_starts_its_own_ranks_when_the_driver_does_not():
+    """`python bench.py --gpus N` without WORLD_SIZE must run N ranks, not one: the launcher starts N fresh
+    processes with the rank environment torch.distributed.run would give them (probed here without a GPU)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rank-probe"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    seen = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in seen] == [0, 1, 2] and all(d["world"] == 3 and d["local_rank"] == d["rank"] for d in seen)
+    assert len({d["port"] for d in seen}) == 1 and seen[0]["master"] == "127.0.0.1"
+    # a WORLD_SIZE that disagrees with --gpus is an error, not a silent one-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-probe"],
+                       env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
