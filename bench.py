@@ -173,17 +173,26 @@ def run_image(w, compute, flags=0):
 
 
 def events_per_call(fn, reps):
-    """Average duration of `fn()` from HIP events on the current stream around `reps` back-to-back calls,
-    after the same number of untimed ones (after an idle gap the chip needs tens of milliseconds to return
-    to its working clock)."""
+    """Average duration of `fn()`: `reps` back-to-back calls captured as one HIP graph on a stream of their
+    own, HIP events on that stream around a replay (the host's launch path, about 10 us per call from
+    Python, stays out of the figure; kernels keep their order and their launch gaps).  The graph runs once
+    untimed first: after an idle gap the chip needs tens of milliseconds to return to its working clock."""
     import torch
-    for _ in range(reps):
-        fn()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-        fn()
-    ev1.record()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+        for _ in range(reps):
+            fn()
+    with torch.cuda.stream(st):
+        graph.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        graph.replay()
+        ev1.record()
     ev1.synchronize()
     return ev0.elapsed_time(ev1) * 1e-3 / reps
 

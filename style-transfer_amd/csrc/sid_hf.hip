@@ -6,7 +6,7 @@
 // independently and two real transforms cost one complex transform.  The whole H x W complex map
 // stays in LDS (128x128: 129 KB); HBM sees each input once and the output once.
 //
-// Square 16/32/64 maps (the decoder ResBlocks of the path) use the radix-8/4 kernel below
+// Square 16/32/64/128 maps (the decoder ResBlocks of the path) use the radix-16/8/4 kernel below
 // (hf2_kernel): each thread does whole radix-R butterflies in registers, and the map makes eight
 // round trips through LDS.  Other shapes use the general kernel:
 //
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) hf_kernel(const void* __restrict__ hcnt, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Square maps, N = R1 * R2 in {4*4, 8*4, 8*8}: two radix stages per line, butterflies in registers.
+// Square maps, N = R1 * R2 in {4*4, 8*4, 8*8, 8*16}: two radix stages per line, butterflies in registers.
 //
 // A line x[n], n = R2*n1 + n2, goes to X[k], k = k1 + R1*k2:
 //   stage 1  for each n2: DFT_R1 over n1 (elements R2 apart), times W_N^(n2*k1), stored at R2*k1 + n2
@@ -245,6 +245,25 @@ struct Dft<8, FWD> {
     }
 };
 
+template <bool FWD>
+struct Dft<16, FWD> {
+    static __device__ __forceinline__ void run(float2 (&v)[16]) {
+        float2 e[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
+        Dft<8, FWD>::run(e);
+        Dft<8, FWD>::run(o);
+        // W16^k = exp(-+ 2 pi i k / 16)
+        constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+        const float2 w[8] = {make_float2(1.f, 0.f), make_float2(c1, -s1), make_float2(h, -h), make_float2(s1, -c1),
+                             make_float2(0.f, -1.f), make_float2(-s1, -c1), make_float2(-h, -h), make_float2(-c1, -s1)};
+#pragma unroll
+        for (int k = 1; k < 8; ++k) o[k] = FWD ? cmul(o[k], w[k]) : cmulc(o[k], w[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = cadd(e[k], o[k]); v[8 + k] = csub(e[k], o[k]); }
+    }
+};
+
 template <bool BF16>
 __device__ __forceinline__ void ld4(const void* p, size_t i, float (&v)[4]) {
     if (BF16) {
@@ -263,12 +282,14 @@ __global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ h
                                                       int pairs_per_b, int radius2) {
     constexpr int R1 = N == 16 ? 4 : 8, R2 = N / R1;
     constexpr int LD = N + 1;
-    __shared__ float2 T[64];                 // exp(-2*pi*i*j/64)
-    __shared__ float2 buf[N * LD];
+    constexpr int TS = N > 64 ? N : 64;
+    extern __shared__ __attribute__((aligned(16))) float2 hf2_lds[];
+    float2* T = hf2_lds;                     // exp(-2*pi*i*j/TS), j < TS
+    float2* buf = hf2_lds + TS;              // N rows of LD
     const int tid = threadIdx.x;
-    if (tid < 64) {
+    if (tid < TS) {
         float s, c;
-        sincospif(-(float)tid / 32.0f, &s, &c);
+        sincospif(-2.0f * (float)tid / (float)TS, &s, &c);
         T[tid] = make_float2(c, s);
     }
     const int b = blockIdx.x / pairs_per_b, pc = blockIdx.x % pairs_per_b;
@@ -278,7 +299,11 @@ __global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ h
     const size_t base_b = base_a + (size_t)N * N;
 
     // ---- load: z = a + i b, rows contiguous, 4 elements per thread and step
-    for (int i = tid; i < N * N / 4; i += THREADS) {
+    constexpr int STEPS = N * N / 4 / THREADS;
+    static_assert(STEPS * THREADS * 4 == N * N, "every thread takes the same number of 4-element steps");
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int i = tid + st * THREADS;
         const int y = (4 * i) / N, x = (4 * i) % N;
         float a[4], bb[4] = {0.f, 0.f, 0.f, 0.f};
         ld4<BF16>(hcnt, base_a + 4 * (size_t)i, a);
@@ -286,10 +311,21 @@ __global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ h
 #pragma unroll
         for (int j = 0; j < 4; ++j) buf[y * LD + x + j] = make_float2(a[j], bb[j]);
     }
+    // the residual operands of the epilogue are requested now, so that their latency passes behind the
+    // transform instead of after it
+    float pre[STEPS][4][4];
+    if (skip) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const size_t o = 4 * (size_t)(tid + st * THREADS);
+            ld4<BF16>(skip, base_a + o, pre[st][0]); ld4<BF16>(hres, base_a + o, pre[st][1]);
+            if (two) { ld4<BF16>(skip, base_b + o, pre[st][2]); ld4<BF16>(hres, base_b + o, pre[st][3]); }
+        }
+    }
     __syncthreads();
 
-    // twiddle W_N^e (forward) from the 64-entry table
-    auto tw = [&](int e) { return T[(e % N) * (64 / N)]; };
+    // twiddle W_N^e (forward) from the table
+    auto tw = [&](int e) { return T[(e % N) * (TS / N)]; };
 
     // One pass over all lines.  ROWS: line = row, positions along x; else line = column.
     // Work item = (line, j): line fastest, so that a wave's lanes touch different lines.
@@ -376,27 +412,26 @@ __global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ h
     stage1_inv(true);
 
     // ---- store: real part -> map a, imaginary part -> map b; fused residual sum
-    for (int i = tid; i < N * N / 4; i += THREADS) {
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const int i = tid + st * THREADS;
         const int y = (4 * i) / N, x = (4 * i) % N;
         const size_t o = 4 * (size_t)i;
         float ra[4], rb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float2 z = buf[y * LD + x + j]; ra[j] = z.x; rb[j] = z.y; }
         if (skip) {
-            float s[4], h[4];
-            ld4<BF16>(skip, base_a + o, s); ld4<BF16>(hres, base_a + o, h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // bf16 tensors: (skip + h) rounds to bf16, then + HF rounds again
-                if (BF16) ra[j] = (float)(__bf16)(s[j] + h[j]) + (float)(__bf16)ra[j];
-                else ra[j] = __fadd_rn(__fadd_rn(s[j], h[j]), ra[j]);
+                if (BF16) ra[j] = (float)(__bf16)(pre[st][0][j] + pre[st][1][j]) + (float)(__bf16)ra[j];
+                else ra[j] = __fadd_rn(__fadd_rn(pre[st][0][j], pre[st][1][j]), ra[j]);
             }
             if (two) {
-                ld4<BF16>(skip, base_b + o, s); ld4<BF16>(hres, base_b + o, h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (BF16) rb[j] = (float)(__bf16)(s[j] + h[j]) + (float)(__bf16)rb[j];
-                    else rb[j] = __fadd_rn(__fadd_rn(s[j], h[j]), rb[j]);
+                    if (BF16) rb[j] = (float)(__bf16)(pre[st][2][j] + pre[st][3][j]) + (float)(__bf16)rb[j];
+                    else rb[j] = __fadd_rn(__fadd_rn(pre[st][2][j], pre[st][3][j]), rb[j]);
                 }
             }
         }
@@ -418,9 +453,15 @@ __global__ void __launch_bounds__(THREADS) hf2_kernel(const void* __restrict__ h
 template <int N, bool BF16>
 int launch_hf2(const void* hcnt, const void* skip, const void* hres, void* out, int B, int C, int radius,
                hipStream_t stream) {
-    constexpr int THREADS = N == 64 ? 256 : (N == 32 ? 128 : 64);
+    constexpr int THREADS = N == 128 ? 512 : (N == 64 ? 512 : (N == 32 ? 256 : 64));
+    constexpr size_t lds = (size_t)((N > 64 ? N : 64) + N * (N + 1)) * sizeof(float2);
+    constexpr auto kern = hf2_kernel<N, THREADS, BF16>;
+    if (lds > 48 * 1024) {
+        const int rc = sid::allow_dynamic_lds<kern>(lds);
+        if (rc != SID_OK) return rc;
+    }
     const int pairs = (C + 1) / 2;
-    hipLaunchKernelGGL((hf2_kernel<N, THREADS, BF16>), dim3(B * pairs), dim3(THREADS), 0, stream, hcnt, skip, hres, out,
+    hipLaunchKernelGGL(kern, dim3(B * pairs), dim3(THREADS), lds, stream, hcnt, skip, hres, out,
                        C, pairs, radius * radius);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
@@ -450,6 +491,7 @@ int dispatch_hf(const void* hcnt, const void* skip, const void* hres, void* out,
     const bool aligned = (((uintptr_t)hcnt | (uintptr_t)out | (uintptr_t)skip | (uintptr_t)hres) & al) == 0;
     const char* e = getenv("SID_TUNE_HF_GENERAL");       // measurement and tests only
     if (H == W && aligned && !(e && e[0] == '1')) {
+        if (H == 128) return launch_hf2<128, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
         if (H == 64) return launch_hf2<64, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
         if (H == 32) return launch_hf2<32, BF16>(hcnt, skip, hres, out, B, C, radius, stream);
         if (H == 16) return launch_hf2<16, BF16>(hcnt, skip, hres, out, B, C, radius, stream);

@@ -1,0 +1,142 @@
+// Would the P.V product of the flash kernel be cheaper as 16x16x32 MFMAs?  At head_dim 40 the product pads
+// its 41 output rows (40 + the ones row) to 64 with 32x32x16 MFMAs (4 per 32-key x 32-query unit) and to 48
+// with 16x16x32 MFMAs (6 per unit, half the work each: 25 % less matrix work), but the probabilities leave
+// the logits MFMA in the 32x32 operand layout and need 4 v_permlane16_swap_b32 per unit to reach the
+// 16x16x32 one.  This models one pipelined slot both ways with the kernel's dependency structure:
+//   A: 2 P.V + 3 K.Q' + 2 P.V  (32x32x16)                 + 16 exp, 8 max3, 8 cvt_pk
+//   B: 3 P.V + 3 K.Q' + 3 P.V  (P.V as 16x16x32)          + the same + 4 permlane16_swap
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_pv16.hip -o ab/ubench_pv16 && ab/ubench_pv16
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MFMA_ZERO(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
+#define MFMA16(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define EXP(d, s) asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(s))
+#define MAX3(x, y, z) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z))
+#define CVT(d, x, y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
+#define SWAP(a, b) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+
+// MODE 0: the kernel's slot (A).  MODE 1: P.V as six 16x16x32 MFMAs plus the swaps (B).
+// MODE 2: B without the swaps (the matrix side alone).  EXTRA: LDS reads, barrier and scalar work as in the kernel.
+template <int MODE, bool EXTRA>
+__global__ void __launch_bounds__(512) bench(float* out, int iters) {
+    f32x16 O0, O1, SA, SB;
+    f32x4 o16[6];
+    for (int i = 0; i < 16; ++i) { O0[i] = O1[i] = SA[i] = SB[i] = 0.f; }
+    for (int j = 0; j < 6; ++j) for (int i = 0; i < 4; ++i) o16[j][i] = 0.f;
+    u32x4 kf[3], qf[3], vf[4], PA[2], PB[2];
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 3; ++j) { kf[j][i] = 0x3c003c00u + threadIdx.x + j; qf[j][i] = 0x3c003c00u + i + j; }
+        for (int j = 0; j < 4; ++j) vf[j][i] = 0x3c003c00u + i * j;
+        for (int j = 0; j < 2; ++j) { PA[j][i] = PB[j][i] = 0x3c003c00u; }
+    }
+    float e[16], m = 0.f;
+    for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    __shared__ u32x4 smem[2048];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) smem[i] = u32x4{1u, 2u, 3u, 4u};
+    __syncthreads();
+    const unsigned laddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (threadIdx.x & 63) * 16;
+    u32x4 fr[7];
+    for (int i = 0; i < 7; ++i) fr[i] = u32x4{0u, 0u, 0u, 0u};
+    unsigned sc0 = blockIdx.x, sc1 = 3;
+    auto ldsread = [&](int i) { if (EXTRA) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[i]) : "v"(laddr) : "memory"); };
+    auto salu = [&](int n) { if (EXTRA) for (int i = 0; i < n; ++i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc0) : "s"(sc1) : "scc"); };
+
+    auto slot = [&](f32x16& Sc, f32x16& Sn, u32x4 (&Pc)[2], u32x4 (&Pp)[2], int u) {
+        if (EXTRA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the 32 vector ops of a unit in the kernel's order, as a flat list of 32 steps
+        auto vop = [&](int k) {
+            const int g = k / 4, r = k % 4;          // group g of 8: exp, exp, max3, cvt(previous group)
+            if (r == 0) EXP(e[2 * g], Sc[2 * g]);
+            else if (r == 1) EXP(e[2 * g + 1], Sc[2 * g + 1]);
+            else if (r == 2) MAX3(m, Sc[2 * g], Sc[2 * g + 1]);
+            else { const int c = (g + 7) % 8; CVT(Pc[c / 4][c % 4], e[2 * c], e[2 * c + 1]); }
+        };
+        auto vops = [&](int a, int b) { for (int k = a; k < b; ++k) vop(k); };
+        if (MODE == 0) {
+            MFMA_ACC(O0, vf[0], Pp[0]); vops(0, 5);
+            MFMA_ACC(O1, vf[1], Pp[0]); vops(5, 10);
+            if (!(u & 1)) { ldsread(3); ldsread(4); }
+            salu(5);
+            MFMA_ZERO(Sn, kf[0], qf[0]); vops(10, 14);
+            MFMA_ACC(Sn, kf[1], qf[1]); vops(14, 19);
+            MFMA_ACC(Sn, kf[2], qf[2]); vops(19, 23);
+            if (!(u & 1)) { ldsread(0); ldsread(1); ldsread(2); }
+            salu(5);
+            MFMA_ACC(O0, vf[2], Pp[1]); vops(23, 28);
+            MFMA_ACC(O1, vf[3], Pp[1]); vops(28, 32);
+            if (!(u & 1)) { ldsread(5); ldsread(6); }
+            salu(5);
+        } else {
+            // P.V of the previous unit: query half 0 reads Pp[0], half 1 reads Pp[1] (after the swaps)
+            MFMA16(o16[0], vf[0], Pp[0]); vops(0, 4);
+            MFMA16(o16[1], vf[1], Pp[0]); vops(4, 8);
+            MFMA16(o16[2], vf[2], Pp[0]); vops(8, 11);
+            if (!(u & 1)) { ldsread(3); ldsread(4); }
+            salu(5);
+            MFMA_ZERO(Sn, kf[0], qf[0]); vops(11, 15);
+            MFMA_ACC(Sn, kf[1], qf[1]); vops(15, 19);
+            MFMA_ACC(Sn, kf[2], qf[2]); vops(19, 23);
+            if (!(u & 1)) { ldsread(0); ldsread(1); ldsread(2); }
+            salu(5);
+            MFMA16(o16[3], vf[0], Pp[1]); vops(23, 26);
+            MFMA16(o16[4], vf[1], Pp[1]); vops(26, 29);
+            MFMA16(o16[5], vf[2], Pp[1]); vops(29, 32);
+            if (MODE == 1) { SWAP(Pc[0][0], Pc[1][0]); SWAP(Pc[0][1], Pc[1][1]); SWAP(Pc[0][2], Pc[1][2]); SWAP(Pc[0][3], Pc[1][3]); }
+            if (!(u & 1)) { ldsread(5); }
+            salu(5);
+        }
+    };
+    for (int it = 0; it < iters; ++it) {
+        slot(SA, SB, PA, PB, 0);
+        slot(SB, SA, PB, PA, 1);
+        slot(SA, SB, PA, PB, 2);
+        if (EXTRA) __syncthreads();
+        slot(SB, SA, PB, PA, 3);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+    float s = m + (float)sc0;
+    for (int i = 0; i < 7; ++i) s += (float)(fr[i][0] + fr[i][3]);
+    for (int i = 0; i < 16; ++i) s += O0[i] + O1[i] + SA[i] + SB[i] + e[i];
+    for (int j = 0; j < 6; ++j) for (int i = 0; i < 4; ++i) s += o16[j][i];
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 4; ++i) s += (float)(PA[j][i] + PB[j][i]);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static float* g_out;
+
+template <int MODE, bool EXTRA>
+void run(const char* name) {
+    const int grid = 256, iters = 4000;
+    for (int threads : {256, 512}) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int i = 0; i < 2; ++i) bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters);
+        (void)hipEventRecord(e0);
+        bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-64s waves/SIMD %d: %7.1f ns per stage (4 slots) per wave\n", name, threads / 256, ms * 1e6 / iters / (threads / 256));
+    }
+}
+
+int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    (void)hipMalloc(&g_out, 256 * 512 * sizeof(float));
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0, false>("A  P.V as 4 x 32x32x16 (the kernel's slot)");
+        run<1, false>("B  P.V as 6 x 16x16x32 + 4 permlane16_swap");
+        run<2, false>("B  without the swaps");
+        run<0, true>("A  + LDS reads, barrier, scalar work");
+        run<1, true>("B  + LDS reads, barrier, scalar work");
+    }
+    return 0;
+}
