@@ -55,7 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "fp32"],
+                    help="bf16 operands; f16 = half-precision query/key operands in the long-sequence kernels; fp32 = split-bf16")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the query / latent tensors")
     ap.add_argument("--store", default="packed", choices=["packed", "tensors"],
                     help="feature store layout of the key/value pairs: the kernels' operand layout, or tensors")
@@ -157,12 +158,14 @@ def injected_call(layer, e, compute, flags=0):
 def run_image(w, compute, flags=0):
     """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
     from style_transfer_amd import ops
+    from style_transfer_amd.attention import resolve_compute
     outs = None
     ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
     for e in range(EVALS):
         for p in w["plain"]:
             q, k, v = p["qkv"][e]
-            ops.plain_attention(q, k, v, p["T"] * p["d"] ** -0.5, HEADS, compute=compute, flags=flags)
+            ls = p["T"] * p["d"] ** -0.5
+            ops.plain_attention(q, k, v, ls, HEADS, compute=resolve_compute(compute, p["N"], p["d"], ls), flags=flags)
         hf_on = HF_FIRST <= e < HF_FIRST + HF_EVALS
         for li, layer in enumerate(w["inj"]):
             if hf_on:
@@ -443,7 +446,8 @@ def run_rank(args, world, rank, local):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.compute == "bf16" else "bf16x3 (f32-grade)",
+            "dtype": {"bf16": "bf16", "f16": "f16 (q.k^T operands of the long-sequence kernels) + bf16",
+                      "fp32": "bf16x3 (f32-grade)"}[args.compute],
             "data": "synthetic",
             "config": {"workload": "configs[1]: one content + char/back style pair, 512^2, gamma=0.5 T=1.5 ratio=0.5, "
                                    "49 UNet evaluations: 6 injected + 10 self attention calls each, fused HF filter "

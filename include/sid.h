@@ -39,6 +39,12 @@ extern "C" {
 /* arithmetic of the two matrix products inside the attention kernels */
 #define SID_COMPUTE_BF16 0  /* bf16 MFMA operands, f32 accumulate: <= 2e-2 relative */
 #define SID_COMPUTE_F32X3 1 /* split-bf16 (hi+lo) 3-product MFMA, f32-grade: <= 1e-3 relative */
+/* Half-precision (f16) operands for the logits product q k^T, bf16 for P V, f32 accumulate: the speed of
+ * SID_COMPUTE_BF16 with eight times finer logits (<= 1e-2 relative also at feature-scale magnitudes,
+ * where bf16 logits cost 2-3e-2).  Scaled queries and keys beyond +-65504 saturate.  Flash path only
+ * (more than 256 keys), head dims 33-48 and 65-80 (else SID_ENOSYS), and
+ * |logit scale * log2(e)| in [2^-10, 2^10] (else SID_EINVAL). */
+#define SID_COMPUTE_F16QK 2
 
 /* memory layout of a (batch, heads, tokens, head_dim) tensor; head_dim is always contiguous */
 #define SID_LAYOUT_BHND 0 /* (B*H, N, d) contiguous: the precomputed feature lists            */

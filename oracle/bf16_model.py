@@ -20,14 +20,24 @@ def bf16_round(a):
     return u.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
+def f16_round(a):
+    """Round float32 values to the nearest IEEE half (saturating at +-65504), returned as float64."""
+    a = np.clip(np.asarray(a, dtype=np.float32), -65504.0, 65504.0)
+    return a.astype(np.float16).astype(np.float64)
+
+
 def _split_heads(x, heads):
     n, c = x.shape
     return np.ascontiguousarray(x.reshape(n, heads, c // heads).transpose(1, 0, 2))
 
 
-def injected_attention_rows(rows, xq, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, m, gamma, T, scale, q_self_coef=0.5):
-    """Rows `rows` of the injected attention with bf16-rounded product operands -> (len(rows), H*d)."""
+def injected_attention_rows(rows, xq, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, m, gamma, T, scale, q_self_coef=0.5,
+                            qk="bf16"):
+    """Rows `rows` of the injected attention with rounded product operands -> (len(rows), H*d).
+    qk: rounding of the scaled queries and the keys, "bf16" or "f16" (SID_COMPUTE_F16QK); the probabilities
+    and values are rounded to bf16 in both."""
     f32 = np.float32
+    rq = bf16_round if qk == "bf16" else f16_round
     rows = np.asarray(rows)
     H, N, d = q_cnt.shape
     qc = np.asarray(q_cnt, f32)[:, rows]
@@ -35,11 +45,11 @@ def injected_attention_rows(rows, xq, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, m, ga
     q = (qc * f32(gamma)).astype(f32) + (q_ * f32(q_self_coef)).astype(f32)         # f32 blend
     c2s = f32(f32(T) * f32(scale)) * LOG2E
     c2c = f32(scale) * LOG2E
-    qs = bf16_round((q * c2s).astype(f32))                                            # query images carry the logit scale
-    qcs = bf16_round((qc * c2c).astype(f32))
-    S1 = np.einsum("hid,hjd->hij", qs, bf16_round(k1))
-    S2 = np.einsum("hid,hjd->hij", qs, bf16_round(k2))
-    SC = np.einsum("hid,hjd->hij", qcs, bf16_round(k_cnt))
+    qs = rq((q * c2s).astype(f32))                                                    # query images carry the logit scale
+    qcs = rq((qc * c2c).astype(f32))
+    S1 = np.einsum("hid,hjd->hij", qs, rq(k1))
+    S2 = np.einsum("hid,hjd->hij", qs, rq(k2))
+    SC = np.einsum("hid,hjd->hij", qcs, rq(k_cnt))
     mm = np.asarray(m, np.float64).reshape(-1)[rows].reshape(1, -1, 1)
     min_cc = SC.min(-1, keepdims=True) / float(c2c) * float(scale)
     b1 = (min_cc - S1.max(-1, keepdims=True) / float(c2s)) * (-mm) * float(LOG2E)
@@ -53,13 +63,14 @@ def injected_attention_rows(rows, xq, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, m, ga
     return np.ascontiguousarray(o.transpose(1, 0, 2).reshape(n, h * dd))
 
 
-def plain_attention_rows(rows, q, k, v, logit_scale):
-    """Rows of softmax((q k^T) * logit_scale) v with bf16-rounded operands.  q (H,Nq,d), k, v (H,Nk,d)."""
+def plain_attention_rows(rows, q, k, v, logit_scale, qk="bf16"):
+    """Rows of softmax((q k^T) * logit_scale) v with rounded operands.  q (H,Nq,d), k, v (H,Nk,d)."""
     f32 = np.float32
     rows = np.asarray(rows)
+    rq = bf16_round if qk == "bf16" else f16_round
     c2 = f32(logit_scale) * LOG2E
-    qs = bf16_round((np.asarray(q, f32)[:, rows] * c2).astype(f32))
-    S = np.einsum("hid,hjd->hij", qs, bf16_round(k))
+    qs = rq((np.asarray(q, f32)[:, rows] * c2).astype(f32))
+    S = np.einsum("hid,hjd->hij", qs, rq(k))
     P = bf16_round(np.exp2(S - S.max(-1, keepdims=True)).astype(f32))
     o = np.einsum("hij,hjd->hid", P, bf16_round(v)) / P.sum(-1, keepdims=True)
     h, n, dd = o.shape

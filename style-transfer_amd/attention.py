@@ -25,11 +25,24 @@ _default_compute = "bf16"
 
 
 def set_default_compute(mode):
-    """'bf16': bf16 MFMA operands (<= 2e-2 rel.), 'fp32': split-bf16 f32-grade products (<= 1e-3)."""
+    """'bf16': bf16 MFMA operands (<= 2e-2 rel.); 'f16': half-precision query/key operands where the
+    library has them (long sequences at head dims 33-48 and 65-80: the injected layers of SD-v1; <= 1e-2
+    also at feature-scale magnitudes, same speed), bf16 elsewhere; 'fp32': split-bf16 f32-grade products
+    (<= 1e-3)."""
     global _default_compute
-    if mode not in ("bf16", "fp32"):
-        raise ValueError("compute mode must be 'bf16' or 'fp32'")
+    if mode not in ("bf16", "f16", "fp32"):
+        raise ValueError("compute mode must be 'bf16', 'f16' or 'fp32'")
     _default_compute = mode
+
+
+def resolve_compute(mode, n_keys, head_dim, logit_scale):
+    """The arithmetic a call runs in: 'f16' falls back to 'bf16' where SID_COMPUTE_F16QK has no kernel
+    (include/sid.h: head dims 33-48 and 65-80, more than 256 keys, |scale * log2(e)| in [2^-10, 2^10])."""
+    if mode != "f16":
+        return mode
+    c2 = abs(logit_scale) * 1.4426950408889634
+    served = (33 <= head_dim <= 48 or 65 <= head_dim <= 80) and n_keys > 256 and 2.0 ** -10 <= c2 <= 2.0 ** 10
+    return "f16" if served else "bf16"
 
 
 class CrossAttention(nn.Module):
@@ -161,10 +174,17 @@ class CrossAttention(nn.Module):
     # The two kernel calls of the module.  (A measurement harness may subclass and override them to
     # time another implementation inside the same network; the package itself has no other path.)
     def _injected(self, xq, feats, m, gamma, T, compute):
+        d = xq.shape[-1] // self.heads
+        compute = resolve_compute(compute, xq.shape[1], d, min(abs(T), 1.0) * self.scale if T else self.scale)
+        if compute == "f16":
+            compute = resolve_compute(compute, xq.shape[1], d, max(abs(T), 1.0) * self.scale)
         return ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute,
                                       flags=self.kernel_flags)
 
     def _plain(self, q, k, v, logit_scale, q_layout, kv_layout, compute):
+        n_keys = k.shape[1]
+        d = (k.shape[-1] // self.heads) if kv_layout == "bnhd" else k.shape[-1]
+        compute = resolve_compute(compute, n_keys, d, logit_scale)
         return ops.plain_attention(q, k, v, logit_scale, self.heads, q_layout=q_layout, kv_layout=kv_layout,
                                    compute=compute, flags=self.kernel_flags)
 

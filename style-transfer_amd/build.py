@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsid.so")
-SOURCES = ["sid_common.cpp", "sid_attn.hip", "sid_attn_bf16.hip", "sid_attn_x3.hip", "sid_attn_small.hip", "sid_mask.hip", "sid_hf.hip", "sid_adain.hip"]
+SOURCES = ["sid_common.cpp", "sid_attn.hip", "sid_attn_bf16.hip", "sid_attn_x3.hip", "sid_attn_f16.hip", "sid_attn_small.hip", "sid_mask.hip", "sid_hf.hip", "sid_adain.hip"]
 HEADERS = [os.path.join(CSRC, "sid_common.h"), os.path.join(CSRC, "sid_attn_kernel.hpp"), os.path.join(ROOT, "include", "sid.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the VGPRs the VALU softmax reads and rescales;

@@ -41,6 +41,18 @@ inline float clamp_scale(float c) {
     return std::fabs(c) < tiny ? (std::signbit(c) ? -tiny : tiny) : c;
 }
 
+// SID_COMPUTE_F16QK keeps the scaled queries in half precision: the logit scale must leave them inside
+// half's normal range, and a kernel instance must exist for the head dim.
+int check_f16qk(int DKS, int DVB, int d, const float* c2, int n) {
+    if (!f16qk_instance(DKS, DVB))
+        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves head dims 33-48 and 65-80 (got %d); use SID_COMPUTE_BF16", d);
+    for (int i = 0; i < n; ++i)
+        if (!(std::fabs(c2[i]) >= 0x1p-10f && std::fabs(c2[i]) <= 0x1p10f))
+            return sid::fail(SID_EINVAL, "SID_COMPUTE_F16QK needs |logit scale * log2(e)| in [2^-10, 2^10] (got %g): "
+                             "use SID_COMPUTE_BF16 for this call", (double)c2[i]);
+    return SID_OK;
+}
+
 __device__ __forceinline__ u32x4 as_u32x4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
 
 // key index inside a 32-key tile that element j of lane-half hh feeds in k-step s2 of P*V
@@ -73,6 +85,7 @@ struct PackParams {
     int njobs;
     int H, d, DKS, DVB;
     int in_bf16;
+    int f16_rows;       // row fragments (Q, K) are written as IEEE half instead of bf16 (SID_COMPUTE_F16QK)
 };
 
 template <bool BF16IN>
@@ -164,6 +177,14 @@ __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
             const float x = load_elem<BF16IN>(J.src, b * J.sb + h * J.sh + (long long)min(row, J.N - 1) * J.sn + min(dv, P.d - 1));
             val[j] = row < J.N ? (dv < P.d ? x : (dv == ones_col ? 1.f : 0.f)) : 0.f;
         }
+    }
+    if (P.f16_rows && J.kind == 0) {
+        // half precision saturates instead of overflowing to infinity (its range ends at 65504)
+        f16x8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)fminf(fmaxf(val[j], -65504.f), 65504.f);
+        J.dst[dst] = __builtin_bit_cast(u32x4, hv);
+        return;
     }
     bf16x8 hi;
 #pragma unroll
@@ -401,7 +422,8 @@ int check_common(int B, int H, int Nq, int Nk, int d, int dtype, int compute) {
     SID_CHECK_ARG(B >= 1 && H >= 1 && Nq >= 1 && Nk >= 1, "B,H,N must be >= 1 (got B=%d H=%d Nq=%d Nk=%d)", B, H, Nq, Nk);
     SID_CHECK_ARG(d >= 1 && d <= 160, "head_dim %d out of range [1,160]", d);
     SID_CHECK_ARG(dtype == SID_DTYPE_F32 || dtype == SID_DTYPE_BF16, "unknown dtype %d", dtype);
-    SID_CHECK_ARG(compute == SID_COMPUTE_BF16 || compute == SID_COMPUTE_F32X3, "unknown compute mode %d", compute);
+    SID_CHECK_ARG(compute == SID_COMPUTE_BF16 || compute == SID_COMPUTE_F32X3 || compute == SID_COMPUTE_F16QK,
+                  "unknown compute mode %d", compute);
     SID_CHECK_ARG((long long)B * H * (long long)std::max(Nq, Nk) * d < (1LL << 31), "tensor too large for 32-bit tile indexing");
     return SID_OK;
 }
@@ -409,7 +431,7 @@ int check_common(int B, int H, int Nq, int Nk, int d, int dtype, int compute) {
 // flash + merge stages shared by the two entry points
 int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, const Stages& stg, const float* mask,
                     void* out, float scale, int B, int H, int Nq, int Nk, int d, int nblk, int dtype, bool x3,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool qk16 = false) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
     fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.nblk = nblk;
@@ -420,7 +442,8 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
     fp.diag = (unsigned long long*)(getenv("SID_DIAG_PTR") ? strtoull(getenv("SID_DIAG_PTR"), nullptr, 0) : 0ull);
 #endif
     if (stg.flash) {
-        const int rc = x3 ? launch_flash_x3(fp, g, stream) : launch_flash_bf16(fp, g, stream);
+        const int rc = x3 ? launch_flash_x3(fp, g, stream)
+                          : (qk16 ? launch_flash_f16qk(fp, g, stream) : launch_flash_bf16(fp, g, stream));
         if (rc != SID_OK) return rc;
     }
     if (!stg.merge || fp.direct) return SID_OK;
@@ -516,12 +539,19 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
 
     // logit scales in the log2 domain; applied to the query images by the pack kernel
     const float c2s = clamp_scale(T * scale * LOG2E), c2c = clamp_scale(scale * LOG2E);
+    const bool qk16 = compute == SID_COMPUTE_F16QK;
+    if (qk16) {
+        const float cs[2] = {c2s, c2c};
+        rc = check_f16qk(g.DKS, g.DVB, d, cs, 2);
+        if (rc != SID_OK) return rc;
+    }
     const bool shift_cols = has_shift_cols(d, g.DKS);    // head dims with a shifted-reference instance
 
     // ---- pack
     if (stg.pack) {
         PackParams pp = {};
         pp.njobs = kv_images ? 2 : 8; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+        pp.f16_rows = qk16;
         long long frags[kMaxJobs];
         auto rowjob = [&](int i, const void* src, u32x4* dst, u32x4* dst_lo, int NT, size_t units) {
             PackJob& j = pp.job[i];
@@ -558,7 +588,7 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
     }
     fp.c2[0] = fp.c2[1] = c2s;
     fp.c2[2] = c2c;
-    return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream);
+    return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream, qk16);
 }
 
 }  // namespace
@@ -611,8 +641,11 @@ extern "C" int sid_pack_kv(const void* k, const void* v, void* image, size_t ima
     carve_kv(g, x3, image, &im);
     if (im.bytes > image_bytes)
         return sid::fail(SID_ENOMEM, "image of %zu bytes is smaller than the %zu required", image_bytes, im.bytes);
+    if (compute == SID_COMPUTE_F16QK && !f16qk_instance(g.DKS, g.DVB))
+        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves head dims 33-48 and 65-80 (got %d); use SID_COMPUTE_BF16", d);
     PackParams pp = {};
     pp.njobs = 2; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+    pp.f16_rows = compute == SID_COMPUTE_F16QK;
     long long frags[kMaxJobs];
     for (int i = 0; i < 2; ++i) {
         PackJob& j = pp.job[i];
@@ -700,6 +733,9 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     const bool x3 = compute == SID_COMPUTE_F32X3;
     constexpr float LOG2E = 1.4426950408889634f;
     if (use_small_path(Nk, d)) {
+        if (compute == SID_COMPUTE_F16QK)
+            return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves key sequences longer than 256 (got %d): use "
+                             "SID_COMPUTE_BF16 or SID_COMPUTE_F32X3 for this call", Nk);
         if (!stg.flash) return SID_OK;
         long long qs[3], ks[3];
         layout_strides(q_layout, H, Nq, d, qs);
@@ -712,12 +748,18 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     Workspace w;
     carve(g, 1, 1, x3, (long long)B * H * Nq, d, workspace, &w);
     const float c2p = clamp_scale(logit_scale * LOG2E);
+    const bool qk16 = compute == SID_COMPUTE_F16QK;
+    if (qk16) {
+        rc = check_f16qk(g.DKS, g.DVB, d, &c2p, 1);
+        if (rc != SID_OK) return rc;
+    }
     if (w.bytes > workspace_bytes)
         return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
 
     if (stg.pack) {
         PackParams pp = {};
         pp.njobs = 3; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+        pp.f16_rows = qk16;
         long long frags[kMaxJobs];
         auto job = [&](int i, const void* src, u32x4* dst, u32x4* dst_lo, int kind, int N, int NT, size_t units, int layout) {
             PackJob& j = pp.job[i];
@@ -741,7 +783,7 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     fp.k[0] = w.k[0][0]; fp.k_lo[0] = w.k[0][1];
     fp.v[0] = w.v[0][0]; fp.v_lo[0] = w.v[0][1];
     fp.c2[0] = c2p;
-    return run_flash_merge(fp, g, w, stg, nullptr, out, 1.f, B, H, Nq, Nk, d, 1, dtype, x3, stream);
+    return run_flash_merge(fp, g, w, stg, nullptr, out, 1.f, B, H, Nq, Nk, d, 1, dtype, x3, stream, qk16);
 }
 
 // ------------------------------------------------------------------------------------------

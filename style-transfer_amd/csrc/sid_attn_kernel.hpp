@@ -123,6 +123,7 @@ constexpr int ring_stages(int DKS, int DVB, bool x3) { return 2; }
 
 int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
+int launch_flash_f16qk(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_merge(const MergeParams& mp, hipStream_t stream);
 
 // Single-launch path for short key sequences (sid_attn_small.hip): reads the caller's tensors
@@ -189,15 +190,28 @@ struct Frags {
     }
 };
 
+// One MFMA of the logits product.  QK16: the query and key images hold IEEE half values (11 significant
+// bits against the 8 of bf16; same MFMA rate); the registers are typed bf16x8 either way, only the bits
+// differ.  The P.V product always takes bf16 operands: the probabilities need bf16's exponent range.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool QK16>
+__device__ __forceinline__ f32x16 mfma_qk(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (QK16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // S^T = K Q^T for one tile of 32 keys x 32 queries.
-template <int DKS, bool X3>
+template <int DKS, bool X3, bool QK16>
 __device__ __forceinline__ f32x16 qk_tile(const Frags<DKS, X3>& kf, const Frags<DKS, X3>& qf) {
+    static_assert(!(X3 && QK16), "the split-operand mode keeps bf16 parts");
     f32x16 S;
 #pragma unroll
     for (int i = 0; i < 16; ++i) S[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < DKS; ++s) {
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[s], qf.hi[s], S, 0, 0, 0);
+        S = mfma_qk<QK16>(kf.hi[s], qf.hi[s], S);
         if (X3) {
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[s], qf.lo[X3 ? s : 0], S, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.lo[X3 ? s : 0], qf.hi[s], S, 0, 0, 0);
@@ -276,7 +290,7 @@ __device__ __forceinline__ void softmax_pv_tile(const f32x16& S, const Frags<2 *
 // One LDS stage of KVS key tiles for the wave's QT query tiles.  Per key tile the K and V fragments
 // are read from LDS once and feed the MFMAs of all QT query tiles; the QT independent softmax
 // chains give the scheduler VALU work to run beside the matrix pipe.
-template <int DKS, int DVB, int KVS, bool X3, int QT, bool TAIL, bool TRACK_MIN, int MODE>
+template <int DKS, int DVB, int KVS, bool X3, int QT, bool TAIL, bool TRACK_MIN, int MODE, bool QK16>
 __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, int key0, int Nk,
                                               const Frags<DKS, X3> (&qf)[QT], f32x16 (&O)[QT][DVB],
                                               RowState (&rs)[QT]) {
@@ -291,7 +305,7 @@ __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, 
         vf.load(L + KU + (j * 2 * DVB) * 64 + lane, PU);
         f32x16 S[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) S[t] = qk_tile<DKS, X3>(kf, qf[t]);
+        for (int t = 0; t < QT; ++t) S[t] = qk_tile<DKS, X3, QK16>(kf, qf[t]);
 #pragma unroll
         for (int t = 0; t < QT; ++t)
             softmax_pv_tile<DVB, X3, TAIL, TRACK_MIN, MODE>(S[t], vf, hh, key0 + 32 * j, Nk, O[t], rs[t]);
@@ -335,7 +349,7 @@ constexpr SoftmaxOps softmax_ops(bool track_min) {
     return t;
 }
 
-template <int DKS, int DVB, int KVS, int QT, bool TRACK_MIN, int MODE>
+template <int DKS, int DVB, int KVS, int QT, bool TRACK_MIN, int MODE, bool QK16>
 struct StagePipe {
     static_assert(KVS % 2 == 0, "fragment registers alternate by key tile parity");
     static_assert(MODE == kFixed || MODE == kShifted, "the reference is frozen in the pipelined loop");
@@ -394,7 +408,7 @@ struct StagePipe {
             for (int c = 0; c < 8; ++c) vf[NVS - 1].hi[i][c] = (__bf16)0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { Pk[1][0][c] = (__bf16)0.f; Pk[1][1][c] = (__bf16)0.f; }
-        S[0] = qk_tile<DKS, false>(kf, qf[0]);
+        S[0] = qk_tile<DKS, false, QK16>(kf, qf[0]);
         if constexpr (QT == 1) {
             load_k(L, 1, lane);
             load_v<0>(L, 0, 0, lane);
@@ -444,9 +458,9 @@ struct StagePipe {
                     f32x16 z;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                    S[sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[0], qf[tn].hi[0], z, 0, 0, 0);
+                    S[sn] = mfma_qk<QK16>(kf.hi[0], qf[tn].hi[0], z);
                 } else {
-                    S[sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.hi[s], qf[tn].hi[s], S[sn], 0, 0, 0);
+                    S[sn] = mfma_qk<QK16>(kf.hi[s], qf[tn].hi[s], S[sn]);
                 }
                 if constexpr (s == DKS - 1 && (u + 2) % QT == 0) {
                     if constexpr (u + 2 < U) load_k(L, (u + 2) / QT, lane);
@@ -489,7 +503,8 @@ __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vm
 
 // SHIFT: the kShifted steady state (head_dim % 16 == 8); a separate instance rather than a run-time
 // branch, because a kernel that carries both steady-state loops no longer fits its registers.
-template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT>
+// QK16: half-precision (f16) query and key images (SID_COMPUTE_F16QK); see mfma_qk.
+template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT, bool QK16>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashParams P) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     constexpr int KU = KVS * DKS * 64;        // u32x4 per stage: K image
@@ -596,7 +611,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 issue_stage(st0 + it + 1, (it + 1) % NB);
                 nissued = it + 2;
             }
-            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE>(lds + (it % NB) * SU, lane, hh,
+            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE, QK16>(lds + (it % NB) * SU, lane, hh,
                                                                    (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
             wait_direct_loads();
             __syncthreads();          // stage it+1 has landed in every wave's view; stage it is free
@@ -612,7 +627,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     auto run_pipe = [&](auto min_c, auto mode_c, int it0, int it1) {
         if constexpr (kPipelined) {
             constexpr int U = KVS * QT;
-            StagePipe<DKS, DVB, KVS, QT, decltype(min_c)::value, decltype(mode_c)::value> pipe;
+            StagePipe<DKS, DVB, KVS, QT, decltype(min_c)::value, decltype(mode_c)::value, QK16> pipe;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see `run`
             for (int k = 1; k < NB; ++k)
                 if (nissued <= it0 + k && it0 + k < slen) { issue_stage(st0 + it0 + k, (it0 + k) % NB); nissued = it0 + k + 1; }
@@ -748,7 +763,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                         Frags<DKS, X3> kf;
                         kf.load(lds + (j * DKS) * 64 + lane, PU);
 #pragma unroll
-                        for (int t = 0; t < QT; ++t) m[t] = fmaxf(m[t], max16(qk_tile<DKS, X3>(kf, qf[t])));
+                        for (int t = 0; t < QT; ++t) m[t] = fmaxf(m[t], max16(qk_tile<DKS, X3, QK16>(kf, qf[t])));
                     }
 #pragma unroll
                     for (int t = 0; t < QT; ++t) rs[t].m2 = fmaxf(m[t], __shfl_xor(m[t], 32));
@@ -758,12 +773,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                     // freeze the reference at a value two bf16 represent exactly and hand it to the MFMA
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        const __bf16 h1 = (__bf16)(-rs[t].m2);
-                        const __bf16 h2 = (__bf16)(-rs[t].m2 - (float)h1);
-                        rs[t].m2 = -((float)h1 + (float)h2);
-                        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                        bf16x2 pr = {h1, h2};
-                        set_shift(t, __builtin_bit_cast(unsigned, pr));
+                        if constexpr (QK16) {
+                            // a half pair; beyond half's range the reference stays at the largest pair (any
+                            // reference is valid, and a logit that outgrows it is caught below like any other)
+                            const float neg = fminf(fmaxf(-rs[t].m2, -60000.f), 60000.f);
+                            const _Float16 h1 = (_Float16)neg;
+                            const _Float16 h2 = (_Float16)(neg - (float)h1);
+                            rs[t].m2 = -((float)h1 + (float)h2);
+                            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+                            f16x2 pr = {h1, h2};
+                            set_shift(t, __builtin_bit_cast(unsigned, pr));
+                        } else {
+                            const __bf16 h1 = (__bf16)(-rs[t].m2);
+                            const __bf16 h2 = (__bf16)(-rs[t].m2 - (float)h1);
+                            rs[t].m2 = -((float)h1 + (float)h2);
+                            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                            bf16x2 pr = {h1, h2};
+                            set_shift(t, __builtin_bit_cast(unsigned, pr));
+                        }
                     }
                     if constexpr (kPipelined) {
                         if (need_min) run_pipe(T_{}, Shifted{}, 0, nfull);
@@ -894,11 +921,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
 }
 
-template <int DKS, int DVB, bool X3, int NW, bool SHIFT>
+template <int DKS, int DVB, bool X3, int NW, bool SHIFT, bool QK16>
 int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     constexpr int KVS = stage_tiles(DKS, DVB, X3);
     constexpr int QT = query_tiles(DKS, DVB, X3);
-    constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT>;
+    constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT, QK16>;
     constexpr size_t lds_need = (size_t)ring_stages(DKS, DVB, X3) * KVS * tile_bytes(DKS, DVB, X3);
     if (lds_need > 48 * 1024) {
         const int rc = sid::allow_dynamic_lds<kern>(lds_need);
@@ -910,25 +937,31 @@ int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stre
     return SID_OK;
 }
 
-template <int DKS, int DVB, bool X3, bool SHIFT>
+template <int DKS, int DVB, bool X3, bool SHIFT, bool QK16>
 int launch_flash_nw(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     switch (g.NW) {
-        case 8: return launch_flash_inst<DKS, DVB, X3, 8, SHIFT>(fp, g, stream);
-        case 4: return launch_flash_inst<DKS, DVB, X3, 4, SHIFT>(fp, g, stream);
-        case 2: return launch_flash_inst<DKS, DVB, X3, 2, SHIFT>(fp, g, stream);
-        default: return launch_flash_inst<DKS, DVB, X3, 1, SHIFT>(fp, g, stream);
+        case 8: return launch_flash_inst<DKS, DVB, X3, 8, SHIFT, QK16>(fp, g, stream);
+        case 4: return launch_flash_inst<DKS, DVB, X3, 4, SHIFT, QK16>(fp, g, stream);
+        case 2: return launch_flash_inst<DKS, DVB, X3, 2, SHIFT, QK16>(fp, g, stream);
+        default: return launch_flash_inst<DKS, DVB, X3, 1, SHIFT, QK16>(fp, g, stream);
     }
 }
 
-template <bool X3>
+// The half-precision logits mode is instantiated for the head dims of the SD-v1 injected layers:
+// 33-48 (DKS 3, DVB 2) and 65-80 (DKS 5, DVB 3).
+constexpr bool f16qk_instance(int DKS, int DVB) { return (DKS == 3 && DVB == 2) || (DKS == 5 && DVB == 3); }
+
+template <bool X3, bool QK16 = false>
 int launch_flash(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     // (DKS, DVB) pairs that contain a head_dim with head_dim % 16 == 8 also have a SHIFT instance
 #define SID_CASE(a, b, has_shift)                                                                            \
-    if (g.DKS == a && g.DVB == b) {                                                                          \
-        if constexpr (has_shift) {                                                                           \
-            if (fp.shift_cols) return launch_flash_nw<a, b, X3, true>(fp, g, stream);                        \
+    if constexpr (!QK16 || f16qk_instance(a, b)) {                                                           \
+        if (g.DKS == a && g.DVB == b) {                                                                      \
+            if constexpr (has_shift) {                                                                       \
+                if (fp.shift_cols) return launch_flash_nw<a, b, X3, true, QK16>(fp, g, stream);              \
+            }                                                                                                \
+            return launch_flash_nw<a, b, X3, false, QK16>(fp, g, stream);                                    \
         }                                                                                                    \
-        return launch_flash_nw<a, b, X3, false>(fp, g, stream);                                              \
     }
     SID_CASE(2, 1, true) SID_CASE(2, 2, false) SID_CASE(3, 2, true) SID_CASE(4, 2, true) SID_CASE(4, 3, false)
     SID_CASE(5, 3, true) SID_CASE(6, 4, false) SID_CASE(8, 5, false) SID_CASE(10, 6, false)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SID_LIB_OVERRIDE") or os.path.join(HERE, "libsid.so")
 
 SID_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
-COMPUTE_BF16, COMPUTE_F32X3 = 0, 1
+COMPUTE_BF16, COMPUTE_F32X3, COMPUTE_F16QK = 0, 1, 2
 LAYOUT_BHND, LAYOUT_BNHD = 0, 1
 STATIC_SCRATCH_BYTES = 64 << 20
 

@@ -23,7 +23,9 @@ def _compute_code(compute):
         return _lib.COMPUTE_BF16
     if compute in ("fp32", "f32", "f32x3", _lib.COMPUTE_F32X3):
         return _lib.COMPUTE_F32X3
-    raise ValueError("compute must be 'bf16' or 'fp32', got %r" % (compute,))
+    if compute in ("f16", "f16qk", _lib.COMPUTE_F16QK):
+        return _lib.COMPUTE_F16QK
+    raise ValueError("compute must be 'bf16', 'f16' or 'fp32', got %r" % (compute,))
 
 
 def _stream(device):

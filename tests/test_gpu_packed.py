@@ -23,7 +23,8 @@ def _inputs(seed, B, H, N, d, dtype=torch.float32):
 
 @pytest.mark.parametrize("B,N,d,compute,dtype", [(1, 4096, 40, "bf16", torch.float32), (1, 1024, 80, "bf16", torch.float32),
                                                  (2, 256, 160, "bf16", torch.float32), (1, 1024, 80, "fp32", torch.float32),
-                                                 (1, 576, 40, "bf16", torch.bfloat16), (1, 100, 64, "fp32", torch.float32)])
+                                                 (1, 576, 40, "bf16", torch.bfloat16), (1, 100, 64, "fp32", torch.float32),
+                                                 (1, 4096, 40, "f16", torch.float32), (1, 1024, 80, "f16", torch.bfloat16)])
 @pytest.mark.parametrize("flags", [0, ops.FLAG_THROUGHPUT])
 def test_packed_equals_unpacked_bit_for_bit(B, N, d, compute, dtype, flags):
     H = 8

@@ -14,7 +14,7 @@ from style_transfer_amd import ops, synth
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"bf16": 2e-2, "fp32": 1e-3}
+TOL = {"bf16": 2e-2, "fp32": 1e-3, "f16": 1e-2}      # "f16": half-precision q, k operands, bf16 P, V
 # bf16 operands: the error of a logit grows with |q||k|, and a peaked softmax turns it into an output
 # error of the same relative size.  Measured (tools/err_dist.py) and reproduced by the operand-rounding
 # model (oracle/bf16_model.py): 5e-3 at unit-scale q, k; 1.2e-2 at twice, 2.5-2.9e-2 at three times that
@@ -97,9 +97,16 @@ def run_injected(case, t, compute, dtype=torch.float32):
 INJ = [c for c in attention_cases() if c["branch"] == "injected" and not c.get("module_weights")]
 
 
-@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+def f16_serves(case):
+    """SID_COMPUTE_F16QK has instances for head dims 33-48 and 65-80."""
+    return 33 <= case["d"] <= 48 or 65 <= case["d"] <= 80
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp32", "f16"])
 @pytest.mark.parametrize("case", INJ, ids=lambda c: f"{c['id']}-N{c['N']}-d{c['d']}")
 def test_injected_attention_vs_reference_golden(case, compute):
+    if compute == "f16" and not f16_serves(case):
+        pytest.skip("no half-precision instance for head_dim %d" % case["d"])
     gold = attention_golden()
     out = run_injected(case, case_inputs(case), compute)
     rows = np.array(case["rows"])
@@ -124,11 +131,12 @@ def test_injected_attention_vs_reference_golden(case, compute):
     ref = orc.injected_attention_rows(probe, t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"],
                                       t["v_cnt"], m, case["gamma"], case["T"], case["d"] ** -0.5)
     assert rel_err(out[probe], ref) < tol
-    if compute == "bf16":
+    if compute in ("bf16", "f16"):
         # the whole difference from the reference is operand rounding: the kernel sits on the model
         import bf16_model
         model = bf16_model.injected_attention_rows(rows, t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"],
-                                                   t["k_cnt"], t["v_cnt"], m, case["gamma"], case["T"], case["d"] ** -0.5)
+                                                   t["k_cnt"], t["v_cnt"], m, case["gamma"], case["T"], case["d"] ** -0.5,
+                                                   qk=compute)
         assert rel_err(out[rows], model) < MODEL_TOL
 
 
@@ -136,9 +144,11 @@ PLAIN = [c for c in attention_cases() if c["branch"] in ("tplain", "plain", "sty
          and not c.get("module_weights")]
 
 
-@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("compute", ["bf16", "fp32", "f16"])
 @pytest.mark.parametrize("case", PLAIN, ids=lambda c: f"{c['id']}-{c['branch']}-N{c['N']}-d{c['d']}")
 def test_plain_attention_vs_reference_golden(case, compute):
+    if compute == "f16" and not (f16_serves(case) and case["N"] > 256):
+        pytest.skip("half-precision operands serve the long-sequence kernels at head dims 33-48 and 65-80")
     gold = attention_golden()
     t = case_inputs(case)
     H, d = case["heads"], case["d"]
@@ -160,7 +170,7 @@ BIG_PLAIN = [c for c in PLAIN if c["N"] == 4096]
 
 
 @pytest.mark.parametrize("flags", [0, ops.FLAG_THROUGHPUT], ids=["default", "throughput"])
-@pytest.mark.parametrize("compute", ["bf16", "fp32"])
+@pytest.mark.parametrize("compute", ["bf16", "fp32", "f16"])
 @pytest.mark.parametrize("case", BIG_PLAIN, ids=lambda c: f"{c['id']}-{c['branch']}-T{c['T']}")
 def test_plain_attention_4096_every_query_tile(case, compute, flags):
     """Single-block attention at Nq = Nk = 4096, head_dim 40 (input blocks 1, 2 of the UNet; 98 calls per
@@ -289,3 +299,26 @@ def test_masked_adain_init_vs_reference_golden():
         b16 = masked_adain_init(g(cnt).bfloat16(), g(char).bfloat16(), g(back).bfloat16(), g(mask)).float().cpu().numpy()
         r = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
         assert rel_err(b16, orc.masked_adain_init(r(cnt), r(char), r(back), mask)) < 2 ** -7, c
+
+
+def test_f16_mode_limits():
+    """SID_COMPUTE_F16QK refuses what it cannot serve instead of degrading silently: other head dims,
+    short key sequences, and logit scales that would push the scaled queries out of half's range."""
+    from style_transfer_amd import lib
+    H, N = 2, 512
+    def qkv(d, n=N):
+        return [g(synth.normal(9000 + i, (H, n, d))) for i in range(3)]
+    for d, n, scale, code in ((64, N, 0.125, -38), (40, 128, 0.158, -38), (40, N, 1e-6, -22), (40, N, 1e5, -22)):
+        q, k, v = qkv(d, n)
+        with pytest.raises(lib.SidError) as e:
+            ops.plain_attention(q, k, v, scale, H, "bhnd", "bhnd", "f16")
+        assert e.value.code == code, (d, n, scale, str(e.value))
+    # large magnitudes saturate instead of producing infinities
+    q, k, v = qkv(40)
+    out = ops.plain_attention(q * 1e6, k, v, 40 ** -0.5, H, "bhnd", "bhnd", "f16")
+    assert torch.isfinite(out).all()
+    # packed images carry the mode
+    kv = ops.pack_kv(k, v, H, "f16")
+    assert kv.compute == lib.COMPUTE_F16QK
+    with pytest.raises(lib.SidError):
+        ops.pack_kv(*qkv(64)[1:], H, "f16")

@@ -31,9 +31,10 @@ def main():
             t = synth.attention_inputs(int(700 + sigma), H, N, d, sigma, 1.0)
             a = (t["xq"][0], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"], mask, 0.5, 1.5, d ** -0.5)
             ref = orc.injected_attention_rows(rows, *a)
-            model = bf16_model.injected_attention_rows(rows, *a)
+            models = {"bf16": bf16_model.injected_attention_rows(rows, *a), "f16": bf16_model.injected_attention_rows(rows, *a, qk="f16")}
             g = {k: torch.from_numpy(v).to(dev) for k, v in t.items()}
-            for compute in ("bf16", "fp32"):
+            for compute in ("bf16", "f16", "fp32"):
+                model = models.get(compute, models["bf16"])
                 out = ops.injected_attention(g["xq"], g["q_cnt"], g["k1"], g["v1"], g["k2"], g["v2"], g["k_cnt"], g["v_cnt"],
                                              torch.from_numpy(mask).to(dev), 0.5, 1.5, d ** -0.5, H, compute=compute)
                 got = out[0].cpu().numpy().astype(np.float64)[rows]
