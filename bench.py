@@ -200,6 +200,26 @@ def events_per_call(fn, reps):
     return ev0.elapsed_time(ev1) * 1e-3 / reps
 
 
+def eager_events_per_call(fn, reps):
+    """Average duration of `fn()` from HIP events on the current stream around `reps` eager back-to-back
+    calls, after as many untimed ones.  For kernels much longer than the host's launch path (about 15 us
+    per call from Python) the queue never drains, so this is the kernel's own launch-to-launch time; it
+    agrees with rocprofv3's per-dispatch durations in the mixed kernel sequence of a real call.  (A HIP
+    graph made of nothing but identical launches of this kernel replays 15 % faster per launch than the
+    same kernel does anywhere else -- any other kernel in the graph removes the effect -- so that figure
+    is not used.)"""
+    import torch
+    for _ in range(reps):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    ev1.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+
 def kernel_records(w, compute):
     """The dominant kernel and its call, alone on the GPU: the flash stage of the injected attention at
     N=4096, d=40, B=1 (HIP events around back-to-back launches of that stage), the whole call as the feature
@@ -207,7 +227,7 @@ def kernel_records(w, compute):
     from style_transfer_amd import ops
     layer = w["inj"][-1]
     injected_call(layer, 0, compute)                                   # a full call fills the workspace
-    t_flash = events_per_call(lambda: injected_call(layer, 0, compute, flags=0x20), 300)      # flash stage only
+    t_flash = eager_events_per_call(lambda: injected_call(layer, 0, compute, flags=0x20), 300)      # flash stage only
     t_call = events_per_call(lambda: injected_call(layer, 0, compute), 300)
     flops = 12.0 * 1 * HEADS * 4096 ** 2 * 40           # 3 QK^T + 3 PV blocks, d = 40 (no padding counted)
     m = w["hf"][-1]

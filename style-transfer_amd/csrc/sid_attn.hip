@@ -352,7 +352,7 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, 
     const int np = nblk * g.KS;                     // rows = B*H*Nq
     w->opart = w->stats = nullptr;
     if (np > 1) {
-        w->opart = (float*)take((size_t)np * rows * d * 4);
+        w->opart = (float*)take((size_t)np * rows * d * (x3 ? 4 : 2));      // halves unless f32-grade
         w->stats = (float*)take((size_t)np * rows * 16);
     }
     w->bytes = off;
@@ -433,6 +433,7 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
                     void* out, float scale, int B, int H, int Nq, int Nk, int d, int nblk, int dtype, bool x3,
                     hipStream_t stream, bool qk16 = false) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
+    fp.part_f16 = !x3;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
     fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.nblk = nblk;
     for (int k = 0; k <= g.W; ++k) fp.bound[k] = g.bound[k];
@@ -449,6 +450,7 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
     if (!stg.merge || fp.direct) return SID_OK;
     MergeParams mp = {};
     mp.opart = w.opart; mp.stats = w.stats; mp.mask = mask; mp.out = out; mp.scale = scale;
+    mp.part_f16 = fp.part_f16;
     for (int b = 0; b < kBlocks; ++b) mp.c2[b] = fp.c2[b];
     mp.B = B; mp.H = H; mp.Nq = Nq; mp.d = d; mp.KS = g.KS; mp.nblk = nblk; mp.out_bf16 = fp.out_bf16;
     return launch_merge(mp, stream);
@@ -795,7 +797,8 @@ namespace sid_attn {
 // times the volume of the writes, are contiguous across the wave.  NP > 0 fixes the number of parts
 // at compile time: all statistics and all partial rows are then requested before the first one is
 // used (one memory round trip per thread instead of one per part).
-template <int VEC, int NP>
+// PART16: the partial rows are halves, normalised by their row sum (a part then weighs w * l).
+template <int VEC, int NP, bool PART16>
 __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const int dpv = P.d / VEC;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -811,7 +814,30 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     constexpr int CAP = NP > 0 ? NP : 1;
     constexpr float LOG2E = 1.4426950408889634f;
     auto stat_ptr = [&](int p) { return (const f32x4*)(P.stats + (((size_t)p * BH + bh) * P.Nq + q) * 4); };
-    auto part_ptr = [&](int p) { return P.opart + (((size_t)p * BH + bh) * P.Nq + q) * P.d + c * VEC; };
+    const size_t part_off = ((size_t)bh * P.Nq + q) * P.d + c * VEC, part_stride = (size_t)BH * P.Nq * P.d;
+    // VEC values of part p as floats
+    auto load_part = [&](int p, float (&o)[VEC]) {
+        if (PART16) {
+            const _Float16* hp = (const _Float16*)P.opart + p * part_stride + part_off;
+            if (VEC == 4) {
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const f16x4 v = *(const f16x4*)hp;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = (float)v[e % 4];
+            } else {
+                o[0] = (float)hp[0];
+            }
+        } else {
+            const float* fp = P.opart + p * part_stride + part_off;
+            if (VEC == 4) {
+                const f32x4 v = *(const f32x4*)fp;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = v[e % 4];
+            } else {
+                o[0] = fp[0];
+            }
+        }
+    };
 
     f32x4 st_[CAP];
     float o_[CAP][VEC];
@@ -819,15 +845,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
 #pragma unroll
         for (int p = 0; p < CAP; ++p) st_[p] = *stat_ptr(p);
 #pragma unroll
-        for (int p = 0; p < CAP; ++p) {
-            if (VEC == 4) {
-                const f32x4 v = *(const f32x4*)part_ptr(p);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) o_[p][e] = v[e % 4];
-            } else {
-                o_[p][0] = *part_ptr(p);
-            }
-        }
+        for (int p = 0; p < CAP; ++p) load_part(p, o_[p]);
     }
     auto stat = [&](int p) { return NP > 0 ? st_[NP > 0 ? p : 0] : *stat_ptr(p); };
 
@@ -881,9 +899,11 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
         for (int p = 0; p < CAP; ++p) {
             const f32x4 st = stat(p);
             const float w = st[1] > 0.f ? __builtin_amdgcn_exp2f(st[0] + bias_of(p) - M2) : 0.f;
-            den += w * (st[1] > 0.f ? st[1] : 0.f);
+            const float wl = w * (st[1] > 0.f ? st[1] : 0.f);
+            den += wl;
+            const float wo = PART16 ? wl : w;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[e] += st[1] > 0.f ? w * o_[p][e] : 0.f;    // an unused slot holds no data
+            for (int e = 0; e < VEC; ++e) acc[e] += st[1] > 0.f ? wo * o_[p][e] : 0.f;    // an unused slot holds no data
         }
     } else {
         for (int p = 0; p < nparts; ++p) {
@@ -894,15 +914,13 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
             const f32x4 st = stat(p);
             if (!(st[1] > 0.f)) continue;
             const float w = __builtin_amdgcn_exp2f(st[0] + bias_of(p) - M2);
-            den += w * st[1];
-            const float* op = part_ptr(p);
-            if (VEC == 4) {
-                const f32x4 o = *(const f32x4*)op;
+            const float wl = w * st[1];
+            den += wl;
+            const float wo = PART16 ? wl : w;
+            float o[VEC];
+            load_part(p, o);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += w * o[e % 4];
-            } else {
-                acc[0] += w * op[0];
-            }
+            for (int e = 0; e < VEC; ++e) acc[e] += wo * o[e];
         }
     }
     const float inv = 1.0f / den;
@@ -922,14 +940,14 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     }
 }
 
-template <int VEC>
+template <int VEC, bool PART16>
 void launch_merge_np(const MergeParams& mp, unsigned blocks, hipStream_t stream) {
     switch (mp.nblk * mp.KS) {
-        case 2: hipLaunchKernelGGL((merge_kernel<VEC, 2>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        default: hipLaunchKernelGGL((merge_kernel<VEC, 0>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 2: hipLaunchKernelGGL((merge_kernel<VEC, 2, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        default: hipLaunchKernelGGL((merge_kernel<VEC, 0, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
     }
 }
 
@@ -937,8 +955,13 @@ int launch_merge(const MergeParams& mp, hipStream_t stream) {
     const int vec = (mp.d & 3) == 0 ? 4 : 1;
     const long long total = (long long)mp.B * mp.H * mp.Nq * (mp.d / vec);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (vec == 4) launch_merge_np<4>(mp, blocks, stream);
-    else launch_merge_np<1>(mp, blocks, stream);
+    if (mp.part_f16) {
+        if (vec == 4) launch_merge_np<4, true>(mp, blocks, stream);
+        else launch_merge_np<1, true>(mp, blocks, stream);
+    } else {
+        if (vec == 4) launch_merge_np<4, false>(mp, blocks, stream);
+        else launch_merge_np<1, false>(mp, blocks, stream);
+    }
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
 }

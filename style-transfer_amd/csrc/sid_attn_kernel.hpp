@@ -49,7 +49,10 @@ struct FlashParams {
     float c2[kBlocks];           // logit scale of each block, log2 domain: x = (q.k) * c2; already applied to
                                  // the packed query images, never zero (the host clamps |c2| >= 2^-40)
     int shift_cols;              // head_dim % 16 == 8: key images carry ones in columns d, d+1
-    float* opart;                // [slot][BH][Nq][d] un-normalised partial outputs, slot = blk * KS + segment
+    float* opart;                // [slot][BH][Nq][d] partial outputs, slot = blk * KS + segment: un-normalised f32, or
+                                 // (part_f16) normalised by the row sum and stored as half -- a convex combination of
+                                 // values, so half's range holds it and its 11 bits sit below the bf16 operand rounding
+    int part_f16;
     float* stats;                // [slot][BH][Nq][4] = (m2, l, smax, smin); l == 0 marks an unused slot
     void* out;                   // (B, Nq, H*d), written here only when direct != 0
     int B, H, Nq, Nk, d;
@@ -71,6 +74,7 @@ struct FlashParams {
 
 struct MergeParams {
     const float* opart;
+    int part_f16;          // partial rows are normalised halves (see FlashParams)
     const float* stats;
     const float* mask;     // (B, Nq) signed mask, or null when nblk == 1
     void* out;             // (B, Nq, H*d)
@@ -119,7 +123,10 @@ constexpr bool pipelined(int DKS, int DVB, bool x3) {
 // ring_stages - 1 stages of compute before it is used).  Two: deeper rings were measured (three and
 // four buffers at head_dim 40) and gain nothing -- the loop waits on LDS fragment reads and on issue
 // slots, not on the copy -- while every extra buffer takes LDS from whatever shares the CU.
-constexpr int ring_stages(int DKS, int DVB, bool x3) { return 2; }
+#ifndef SID_RING
+#define SID_RING 2
+#endif
+constexpr int ring_stages(int DKS, int DVB, bool x3) { return SID_RING; }
 
 int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
@@ -882,6 +889,29 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         } else {
             const size_t row = ((size_t)part * BH + bh) * P.Nq + q;
             float* op = P.opart + row * d;
+            if (P.part_f16) {
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                _Float16* oh = (_Float16*)P.opart + row * d;
+                const float inv = 1.0f / lsum;
+                auto sat = [](float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); };
+#pragma unroll
+                for (int b = 0; b < DVB; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int dv0 = 32 * b + 8 * g + 4 * hh;
+                        if (vec) {
+                            if (dv0 < d) {
+                                f16x4 o = {sat(O[t][b][4 * g] * inv), sat(O[t][b][4 * g + 1] * inv), sat(O[t][b][4 * g + 2] * inv),
+                                           sat(O[t][b][4 * g + 3] * inv)};
+                                *(f16x4*)(oh + dv0) = o;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (dv0 + e < d) oh[dv0 + e] = sat(O[t][b][4 * g + e] * inv);
+                        }
+                    }
+            } else
 #pragma unroll
             for (int b = 0; b < DVB; ++b)
 #pragma unroll

@@ -20,26 +20,23 @@ def variant(extra_flags=0, plain=True, hf=True, inj=(True, True), plain_keep=lam
         if not torch.cuda.is_current_stream_capturing():
             return full(w, compute, flags)
         outs = None
-        for z in w["z"]:
-            ops.masked_adain(z[0], z[1], z[2], w["mask512"])
+        ops.masked_adain(w["z"][0], w["z"][1], w["z"][2], w["mask512"])
         for e in range(bench.EVALS):
             if plain:
                 for p in w["plain"]:
                     if not plain_keep(p["N"]):
                         continue
-                    ops.plain_attention(p["q"], p["k"], p["v"], p["T"] * p["d"] ** -0.5, bench.HEADS, compute=compute,
+                    q, k, v = p["qkv"][e]
+                    ops.plain_attention(q, k, v, p["T"] * p["d"] ** -0.5, bench.HEADS, compute=compute,
                                         flags=flags | extra_flags)
-            hf_on = e >= bench.EVALS - bench.HF_EVALS
+            hf_on = bench.HF_FIRST <= e < bench.HF_FIRST + bench.HF_EVALS
             for li, layer in enumerate(w["inj"]):
                 if hf_on and hf:
                     m = w["hf"][li]
-                    ops.hf_filter(m["h_cnt"][e - (bench.EVALS - bench.HF_EVALS)], bench.RATIO, skip=m["skip"], h=m["h"])
+                    ops.hf_filter(m["h_cnt"][e - bench.HF_FIRST], bench.RATIO, skip=m["skip"], h=m["h"])
                 if not inj[0 if layer["N"] == 4096 else 1]:
                     continue
-                f = layer["feats"][e]
-                outs = ops.injected_attention(layer["xq"], f[0], f[1], f[2], f[3], f[4], f[5], f[6], layer["mask"],
-                                              bench.GAMMA, bench.TEMP, layer["d"] ** -0.5, bench.HEADS, compute=compute,
-                                              flags=flags | extra_flags)
+                outs = bench.injected_call(layer, e, compute, flags | extra_flags)
         return outs
     return run
 
@@ -57,11 +54,11 @@ if os.environ.get("ABLATE_NO_THROUGHPUT_FLAG") == "1":
     ops.FLAG_THROUGHPUT = 0
 if os.environ.get("ABLATE_CASES"):
     CASES = [c for i, c in enumerate(CASES) if str(i) in os.environ["ABLATE_CASES"].split(",")]
-sys.argv = [sys.argv[0], "--no-cpu-baseline", "--steps", os.environ.get("ABLATE_STEPS", "45"), "--warmup", "15", "--in-flight", lanes]
+sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-e2e", "--steps", os.environ.get("ABLATE_STEPS", "45"), "--warmup", "15", "--in-flight", lanes]
 for name, fn in CASES:
     bench.run_image = fn
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        bench.main()
+        bench.main(sys.argv[1:])
     line = json.loads(buf.getvalue().strip().splitlines()[-1])
     print("%-36s %6.1f imgs/s  %6.2f ms per image" % (name, line["value"], line["ms_per_step"]), flush=True)

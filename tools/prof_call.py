@@ -1,0 +1,49 @@
+"""The injected attention call as a feature store serves it (key/value pairs pre-packed), timed the way the
+path runs it: a HIP graph of back-to-back calls.  Prints the whole call (query pack + flash + merge) and
+the flash stage alone (back-to-back launches keep its K/V images in L2, so it reads faster than in a call).
+    python tools/prof_call.py [N d B reps compute flags]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from style_transfer_amd import ops
+N, d, B, reps = (int(sys.argv[i]) if len(sys.argv) > i else v for i, v in ((1, 4096), (2, 40), (3, 1), (4, 200)))
+compute = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+base_flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+H = 8
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(0)
+rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+xq = rn(B, N, H * d)
+q_cnt = rn(B * H, N, d)
+kv = [ops.pack_kv(rn(B * H, N, d), rn(B * H, N, d), H, compute) for _ in range(3)]
+m = torch.sign(rn(B, N)).contiguous()
+out = torch.empty_like(xq)
+
+
+def call(flags=0):
+    return ops.injected_attention_packed(xq, q_cnt, kv[0], kv[1], kv[2], m, 0.5, 1.5, d ** -0.5, H, out=out, flags=flags | base_flags)
+
+
+def graph_time(fn):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        for _ in range(reps):
+            fn()
+    with torch.cuda.stream(st):
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); graph.replay(); e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+fl = 12.0 * B * H * N * N * d
+t_call = graph_time(call)
+t_flash = graph_time(lambda: call(0x20))
+print("N=%d d=%d B=%d %s: call %.1f us (%.0f TF/s = %.1f%% of 2.5 PF) | flash stage alone %.1f us (%.1f%%)" % (
+    N, d, B, compute, t_call, fl / t_call / 1e6, fl / t_call / 2.5e9 * 100, t_flash, fl / t_flash / 2.5e9 * 100))
