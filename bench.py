@@ -204,10 +204,9 @@ def eager_events_per_call(fn, reps):
     """Average duration of `fn()` from HIP events on the current stream around `reps` eager back-to-back
     calls, after as many untimed ones.  For kernels much longer than the host's launch path (about 15 us
     per call from Python) the queue never drains, so this is the kernel's own launch-to-launch time; it
-    agrees with rocprofv3's per-dispatch durations in the mixed kernel sequence of a real call.  (A HIP
-    graph made of nothing but identical launches of this kernel replays 15 % faster per launch than the
-    same kernel does anywhere else -- any other kernel in the graph removes the effect -- so that figure
-    is not used.)"""
+    agrees with rocprofv3's per-dispatch durations in the mixed kernel sequence of a real call.  The
+    calls run on the stream whose workspace the preceding full call filled: a flash stage that reads an
+    unfilled (zero) workspace draws less power and runs 17 % faster, which is not a measurement."""
     import torch
     for _ in range(reps):
         fn()

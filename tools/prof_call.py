@@ -1,6 +1,6 @@
 """The injected attention call as a feature store serves it (key/value pairs pre-packed), timed the way the
 path runs it: a HIP graph of back-to-back calls.  Prints the whole call (query pack + flash + merge) and
-the flash stage alone (back-to-back launches keep its K/V images in L2, so it reads faster than in a call).
+the flash stage alone.
     python tools/prof_call.py [N d B reps compute flags]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,8 @@ def call(flags=0):
 def graph_time(fn):
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
-        for _ in range(3):
+        call()                      # a full call first: this stream's workspace must hold real query images
+        for _ in range(3):          # (a flash stage fed zeros draws less power and runs 17 % faster)
             fn()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
