@@ -74,3 +74,37 @@ def test_head_dims_served_by_a_larger_instance(d, compute, tol):
     pl = ops.plain_attention(q, k, v, d ** -0.5, H, "bhnd", "bhnd", compute)[0].cpu().numpy()
     pref = orc.plain_attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), d ** -0.5, dtype=np.float64)
     assert rel_err(pl, pref) < tol
+
+
+def test_graph_replay_matches_eager_call_sequence():
+    """The launch sequence of a call (query pack -> flash -> merge, then a dependent second call that reads
+    the first one's output) captured as a HIP graph and replayed on fresh inputs gives the eager results:
+    the kernels of a call keep their order inside a graph, which the benchmark's image graphs rely on."""
+    H, N, d = 8, 1024, 80
+    _, g, m = _inputs(3600, 1, H, N, d)
+    kv = [ops.pack_kv(g[k], g[v], H, "bf16") for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    xq = g["xq"].clone()
+    out1, out2 = torch.empty_like(xq), torch.empty_like(xq)
+
+    def seq():
+        ops.injected_attention_packed(xq, g["q_cnt"], kv[0], kv[1], kv[2], m, 0.5, 1.5, d ** -0.5, H, out=out1)
+        ops.injected_attention_packed(out1, g["q_cnt"], kv[1], kv[0], kv[2], m, 0.75, 1.0, d ** -0.5, H, out=out2)
+        ops.plain_attention(out2, xq, out1, d ** -0.5, H, out=out1)
+
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        seq()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        seq()
+    for trial in range(3):
+        xq.copy_(torch.roll(g["xq"], 11 * (trial + 1), dims=1))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        got1, got2 = out1.clone(), out2.clone()
+        with torch.cuda.stream(st):
+            seq()
+        torch.cuda.synchronize()
+        assert torch.equal(got1, out1) and torch.equal(got2, out2), trial
