@@ -300,23 +300,37 @@ def e2e_record(dev, compute, store):
     ctx = torch.randn(1, 77, 768, device=dev, generator=g)
     mask_dev = torch.from_numpy(mask).to(dev)
 
-    def one():
-        x_T = masked_adain_init(z[0], z[1], z[2], mask_dev)
-        return s.sample(x_T, ctx, injected_features=merged, start_step=49)
+    def timed(sampler, images=2):
+        def one():
+            x_T = masked_adain_init(z[0], z[1], z[2], mask_dev)
+            return sampler.sample(x_T, ctx, injected_features=merged, start_step=49)
+        one()                            # warm-up: the convolution library picks its kernels here (and graph capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(images):
+            out = one()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        return (time.perf_counter() - t0) / images
 
-    one()                                # warm-up: the convolution library picks its kernels here
-    torch.cuda.synchronize()
-    images = 2
-    t0 = time.perf_counter()
-    for _ in range(images):
-        out = one()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / images
-    assert torch.isfinite(out).all()
-    return {"value": 1.0 / dt, "unit": "imgs/s", "s_per_image": dt, "images": images,
+    dt = timed(s)
+    # the same loop with every evaluation replayed as one HIP graph over static slots (graphed.GraphedUNet):
+    # the eager host network is bound by its ~700 launches per evaluation, not by the GPU
+    from style_transfer_amd.graphed import GraphedUNet
+    sg = DDIMSampler(GraphedUNet(model))
+    sg.make_schedule(50, 0.0)
+    dt_g = timed(sg)
+    with torch.autocast("cuda", dtype=torch.bfloat16):     # the host network's convolutions and linears in bf16
+        sa = DDIMSampler(GraphedUNet(model))
+        sa.make_schedule(50, 0.0)
+        dt_a = timed(sa)
+    return {"value": 1.0 / dt_g, "unit": "imgs/s", "s_per_image": dt_g, "images": 2,
+            "eager_host_unet": {"value": 1.0 / dt, "s_per_image": dt},
+            "bf16_autocast_host_unet": {"value": 1.0 / dt_a, "s_per_image": dt_a},
             "what": "masked AdaIN init + 49 evaluations of the host UNet (SD-v1 size, random fp32 weights, stock "
-                    "PyTorch convolutions) with the HIP attention kernels, one image at a time, no graph; VAE and "
-                    "text encoder not run"}
+                    "PyTorch convolutions) with the HIP attention kernels, one image at a time, every evaluation "
+                    "replayed as one HIP graph (eager_host_unet: the same launched kernel by kernel; "
+                    "bf16_autocast_host_unet: graphs captured under bf16 autocast); VAE and text encoder not run"}
 
 
 def cpu_baseline():

@@ -57,6 +57,7 @@ def build_parser():
                    help="attention kernel arithmetic: bf16 operands; f16 = half-precision query/key operands in the injected "
                         "layers (same speed, finer logits); fp32 = split-bf16, f32-grade")
     p.add_argument('--feature_dtype', default='float32', choices=['float32', 'bfloat16'], help="storage type of the feature store in HBM")
+    p.add_argument('--graph_unet', action='store_true', help="replay every UNet evaluation as one HIP graph (not with a residual file)")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
@@ -138,6 +139,16 @@ def stylise(opt, model, sampler, triple, uc, device):
     else:
         from .high_frequency import unpatch_decoder_resblocks
         unpatch_decoder_resblocks(model)                               # a patch left by the previous image
+    if opt.graph_unet and callback is None:
+        from .graphed import GraphedUNet
+        graphed = getattr(sampler, "_graphed", None)
+        if graphed is None:
+            graphed = sampler._graphed = GraphedUNet(model)
+        eager, sampler.unet = sampler.unet, graphed
+        try:
+            return sampler.sample(x_T, uc, injected_features=feats, start_step=opt.start_step)
+        finally:
+            sampler.unet = eager
     return sampler.sample(x_T, uc, injected_features=feats, start_step=opt.start_step, callback=callback)
 
 

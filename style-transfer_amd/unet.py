@@ -41,10 +41,19 @@ def route_injected(injected_features, block_idx):
     return kw, injected_features.get("output_block_%d_out_layers" % block_idx)
 
 
+_FREQS = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000):
     """[cos | sin] sinusoidal embedding (ldm/modules/diffusionmodules/util.py:151-171)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+    key = (dim, max_period, str(timesteps.device))
+    freqs = _FREQS.get(key)
+    if freqs is None:
+        # computed on the CPU as the reference does, then kept on the device (no host copy per call, so an
+        # evaluation can be captured in a HIP graph)
+        freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+        _FREQS[key] = freqs
     args = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
