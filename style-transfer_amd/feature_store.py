@@ -170,7 +170,10 @@ class FeatureStore:
             for entry in feats:
                 for key in [k for k in entry if k.endswith("_self_attn_k") and torch.is_tensor(entry[k])]:
                     vkey = key[:-1] + "v"
-                    kv = ops.pack_kv(entry[key].contiguous(), entry[vkey].contiguous(), heads, compute)
+                    d = entry[key].shape[-1]
+                    # half-precision operands exist for head dims 33-48 and 65-80; other layers take bf16
+                    mode = "bf16" if compute == "f16" and not (33 <= d <= 48 or 65 <= d <= 80) else compute
+                    kv = ops.pack_kv(entry[key].contiguous(), entry[vkey].contiguous(), heads, mode)
                     entry[key] = entry[vkey] = kv
         return self
 
