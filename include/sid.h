@@ -51,7 +51,13 @@ extern "C" {
 #define SID_LAYOUT_BNHD 1 /* (B, N, H*d) contiguous: the output of a Linear projection        */
 
 /* flags (bit mask) */
-#define SID_FLAG_BLOCK_SKIP 1 /* reserved: skip key blocks whose weight underflows f32 */
+/* Injected attention only: leave out a key block for a workgroup of queries when its whole softmax mass is
+ * provably below half an ulp of the f32 row sums (bounds from sampled logits, 45 log2 units of margin;
+ * the content block is predicted and then verified with its exact maximum, and still delivers min cc).
+ * At feature-scale logits one style block is dead on every row with |mask| = 1.  Results change by less
+ * than f32 rounding.  Takes effect with SID_COMPUTE_BF16 / F16QK, T > 0, scale > 0, N >= 64; elsewhere the
+ * flag is ignored.  Workgroups then hold 256 queries. */
+#define SID_FLAG_BLOCK_SKIP 1
 /* The call shares the GPU with other work of the caller (other streams): choose the decomposition
  * with the least total work (no key-range splits, fewer partial results) instead of the one that
  * fills an otherwise idle GPU. */
@@ -152,6 +158,14 @@ int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt,
                                  int B, int H, int N, int d,
                                  float gamma, float q_self_coef, float T, float scale,
                                  int dtype, int compute, int flags, void* stream);
+
+/*
+ * Where the four block-skipping counters of the last sid_injected_attn_fwd[_packed] call with these
+ * arguments sit in its workspace (byte offset of 4 x uint32: key-block segments dropped, content segments
+ * reduced to their logits, such segments redone in full, segments seen), or -1 when the flag has no effect.
+ * No counterpart in the reference: measurement and tests.
+ */
+long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int compute, int flags, int packed);
 
 /*
  * How a call would be decomposed (host arithmetic only, nothing is launched): for

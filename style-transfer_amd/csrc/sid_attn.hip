@@ -86,6 +86,14 @@ struct PackParams {
     int H, d, DKS, DVB;
     int in_bf16;
     int f16_rows;       // row fragments (Q, K) are written as IEEE half instead of bf16 (SID_COMPUTE_F16QK)
+    // SID_FLAG_BLOCK_SKIP: the first rm_blocks blocks of the launch (one per image) regroup the tokens by
+    // mask side instead of packing
+    const float* rm_mask;   // (B, N)
+    int* rm_out;            // [B][rm_NP]
+    int* rm_groups;         // [B]
+    unsigned* rm_counters;  // the call's four skip counters, zeroed here
+    int rm_blocks, rm_N, rm_NP, rm_GR;
+    float rm_ts;
 };
 
 template <bool BF16IN>
@@ -94,12 +102,83 @@ __device__ __forceinline__ float load_elem(const void* p, long long idx) {
     return ((const float*)p)[idx];
 }
 
+// Regrouping of one image's tokens by mask side: [m > ts | in between | m < -ts], stable, every side
+// starting on a multiple of GR positions (the queries of one workgroup) with -1 in the gaps.  A region
+// boundary cuts through the rows of the feature map, so in token order most workgroups straddle it;
+// regrouped, none does, and a workgroup can drop the style block of the far side for all its rows.  Only
+// the order in which workgroups pick up queries changes: the images stay in token order.
+__device__ void rowmap_block(const PackParams& P, int b) {
+    constexpr int kThreads = 256, kWaves = kThreads / 64;
+    __shared__ int wave_sum[3][kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = P.rm_N, GR = P.rm_GR;
+    const float* m = P.rm_mask + (size_t)b * N;
+    int* out = P.rm_out + (size_t)b * P.rm_NP;
+    const float ts = P.rm_ts;
+    auto cls = [&](float v) { return v > ts ? 0 : (v < -ts ? 2 : 1); };
+    // every thread owns a run of consecutive tokens, so positions inside a side keep the token order
+    const int per = (N + kThreads - 1) / kThreads;
+    const int r0 = min(N, tid * per), r1 = min(N, r0 + per);
+    int cnt[3] = {0, 0, 0};
+    for (int r = r0; r < r1; ++r) {
+        const int c = cls(m[r]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cnt[k] += c == k;
+    }
+    int before[3];                 // tokens of the side in lower threads of this wave
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v = cnt[k];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(v, off);
+            if (lane >= off) v += t;
+        }
+        before[k] = v - cnt[k];
+        if (lane == 63) wave_sum[k][wv] = v;
+    }
+    __syncthreads();
+    int start = 0, first[3], total[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int lower = 0;
+        total[k] = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int n = wave_sum[k][w];
+            lower += w < wv ? n : 0;
+            total[k] += n;
+        }
+        first[k] = start;
+        before[k] += start + lower;
+        start += (total[k] + GR - 1) / GR * GR;
+    }
+    for (int r = r0; r < r1; ++r) {
+        const int c = cls(m[r]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (c == k) out[before[k]++] = r;
+    }
+    for (int p = tid; p < P.rm_NP; p += kThreads) {
+        bool gap = p >= start;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gap |= p >= first[k] + total[k] && p < first[k] + (total[k] + GR - 1) / GR * GR;
+        if (gap) out[p] = -1;
+    }
+    if (tid == 0) P.rm_groups[b] = start / GR;
+    if (b == 0 && tid < 4) P.rm_counters[tid] = 0u;
+}
+
 // One thread per 16-byte fragment.  Row fragments (Q, K) are 8 consecutive elements of one source
 // row, so threads are ordered (tile, row, chunk): consecutive lanes read consecutive 32-byte chunks of
 // a row (coalesced, two 16-byte loads each when the rows allow it) and scatter their fragment to its
 // place in the image.  V^T fragments gather 8 keys of one column; lanes run along the row there.
 template <bool BF16IN>
 __global__ void __launch_bounds__(256) pack_kernel(PackParams P) {
+    if ((int)blockIdx.x < P.rm_blocks) {          // first in the launch: they take longest
+        rowmap_block(P, (int)blockIdx.x);
+        return;
+    }
     int jb = 0;
 #pragma unroll
     for (int i = 1; i < kMaxJobs; ++i)
@@ -237,7 +316,8 @@ Tune tune() {
 // Decomposition of one call: waves per workgroup and key splits -- sized so the grid covers the
 // 256 CUs with about two waves per SIMD while as many queries as possible share each K/V stage.
 // SID_TUNE_NW / SID_TUNE_KS override the choice (measurement only).
-int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool throughput, Geometry* g) {
+// `skip`: block skipping is on; the run table of two blocks is filled in as well.
+int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool throughput, Geometry* g, bool skip = false) {
     if (!supported_dims(d, &g->DKS, &g->DVB))
         return sid::fail(SID_ENOSYS, "head_dim %d has no kernel instance (supported: 1-160)", d);
     g->KVS = stage_tiles(g->DKS, g->DVB, x3);
@@ -274,7 +354,8 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     };
     int W = nblk;
     if (!throughput) {
-        const long long pairs = BH * g->nQG, slots = 512LL * 4 / nw;      // two waves per SIMD
+        // (block skipping launches up to kSkipPadGroups more query groups: they must fit the same rounds)
+        const long long pairs = BH * (g->nQG + (skip ? kSkipPadGroups : 0)), slots = 512LL * 4 / nw;      // two waves per SIMD
         double best = 1e30;
         for (int w = 1; w <= 8 * nblk && w <= T; ++w) {
             const int G_ = (T + w - 1) / w;
@@ -294,32 +375,41 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     // 6-7 us against 1.3 us per stage at head_dim 40).  c(s) = s + kSwitch * (block boundaries before
     // s) is cut at its W-quantiles; a cut that falls into the cost of a change sits on the boundary.
     constexpr double kSwitch = 5.0;
-    const double ctot = T + kSwitch * (nblk - 1);
-    g->bound[0] = 0;
-    for (int k = 1; k <= W; ++k) {
-        const double x = ctot * k / W;
-        int s = T;
-        for (int b = 0; b < nblk; ++b) {
-            const double lo = b * (stages + kSwitch);
-            if (x <= lo) { s = b * stages; break; }
-            if (x < lo + stages) { s = b * stages + (int)std::lround(x - lo); break; }
+    g->KS = 1;
+    auto cut = [&](int nb, unsigned short* bound, unsigned char* first_run, unsigned char* nseg) {
+        const int Tn = nb * stages;
+        const double ctot = Tn + kSwitch * (nb - 1);
+        bound[0] = 0;
+        for (int k = 1; k <= W; ++k) {
+            const double x = ctot * k / W;
+            int s = Tn;
+            for (int b = 0; b < nb; ++b) {
+                const double lo = b * (stages + kSwitch);
+                if (x <= lo) { s = b * stages; break; }
+                if (x < lo + stages) { s = b * stages + (int)std::lround(x - lo); break; }
+            }
+            s = std::max(s, (int)bound[k - 1] + 1);       // every run holds a stage ...
+            s = std::min(s, Tn - (W - k));                  // ... and leaves one for each run after it
+            bound[k] = (unsigned short)s;
         }
-        s = std::max(s, (int)g->bound[k - 1] + 1);       // every run holds a stage ...
-        s = std::min(s, T - (W - k));                      // ... and leaves one for each run after it
-        g->bound[k] = (unsigned short)s;
-    }
+        for (int b = 0; b < nb; ++b) {
+            int first = -1, n = 0;
+            for (int k = 0; k < W; ++k)
+                if (bound[k] < (b + 1) * stages && bound[k + 1] > b * stages) { if (first < 0) first = k; ++n; }
+            first_run[b] = (unsigned char)first;
+            nseg[b] = (unsigned char)n;
+            g->KS = std::max(g->KS, n);
+        }
+    };
+    for (int b = 0; b < kBlocks; ++b) { g->first_run[b] = 0; g->nseg[b] = 0; }
+    cut(nblk, g->bound, g->first_run, g->nseg);
     g->G = 0;
     for (int k = 0; k < W; ++k) g->G = std::max(g->G, (int)g->bound[k + 1] - (int)g->bound[k]);
-    g->KS = 1;
-    for (int b = 0; b < kBlocks; ++b) { g->first_run[b] = 0; g->nseg[b] = 0; }
-    for (int b = 0; b < nblk; ++b) {
-        int first = -1, n = 0;
-        for (int k = 0; k < W; ++k)
-            if (g->bound[k] < (b + 1) * stages && g->bound[k + 1] > b * stages) { if (first < 0) first = k; ++n; }
-        g->first_run[b] = (unsigned char)first;
-        g->nseg[b] = (unsigned char)n;
-        g->KS = std::max(g->KS, n);
-    }
+    // block skipping: a query group whose one style block is dead runs the other two blocks with the same
+    // W workgroups (W <= 2 * stages because W <= T and skipping is only on for long blocks)
+    for (int k = 0; k <= kMaxRuns; ++k) g->bound2[k] = 0;
+    for (int b = 0; b < 2; ++b) { g->first_run2[b] = 0; g->nseg2[b] = 0; }
+    if (skip && nblk == kBlocks && W <= 2 * stages) cut(2, g->bound2, g->first_run2, g->nseg2);
     g->NKT = stages * g->KVS;                             // whole stages; surplus tiles are zero
     g->lds = (size_t)ring_stages(g->DKS, g->DVB, x3) * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
     g->q_units = (size_t)BH * g->NQT * g->DKS * 64;
@@ -328,12 +418,19 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     return SID_OK;
 }
 
+// positions per image in the regrouped token order: the launch's query groups, padding included
+size_t skip_positions(const Geometry& g) { return (size_t)(g.nQG + kSkipPadGroups) * g.NW * g.QT * 32; }
+
 struct Workspace {
     u32x4* q[2][2];              // [which: 0 blended, 1 content][part: hi, lo]
     u32x4* k[kBlocks][2];
     u32x4* v[kBlocks][2];
     float* opart;                // [parts][BH][Nq][d]
     float* stats;                // [parts][BH][Nq][4]
+    int* rowmap;                 // block skipping: [B][NP] token order, [B] groups in use, 4 counters
+    int* rowmap_groups;
+    unsigned* skip_count;
+    size_t skip_count_off;
     size_t bytes;
 };
 
@@ -354,6 +451,14 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, 
     if (np > 1) {
         w->opart = (float*)take((size_t)np * rows * d * (x3 ? 4 : 2));      // halves unless f32-grade
         w->stats = (float*)take((size_t)np * rows * 16);
+    }
+    w->rowmap = w->rowmap_groups = nullptr; w->skip_count = nullptr; w->skip_count_off = 0;
+    if (nblk == kBlocks) {
+        const size_t BH = g.q_units / ((size_t)g.DKS * 64) / g.NQT;
+        w->skip_count_off = off;
+        w->skip_count = (unsigned*)take(256);
+        w->rowmap_groups = (int*)take(BH * 4);                       // B entries would do; B is not known here
+        w->rowmap = (int*)take(BH * skip_positions(g) * 4);
     }
     w->bytes = off;
 }
@@ -390,8 +495,9 @@ bool use_small_path(int Nk, int d) {
     return small_attn_supported(Nk, d) && !tune().no_small;
 }
 
-int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream) {
-    int blocks = 0;
+int launch_pack(PackParams& pp, const long long* frags, hipStream_t stream, int rm_images = 0) {
+    pp.rm_blocks = pp.rm_out ? rm_images : 0;
+    int blocks = pp.rm_blocks;
     for (int i = 0; i < pp.njobs; ++i) {
         PackJob& j = pp.job[i];
         j.first_block = blocks;
@@ -434,7 +540,8 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
                     hipStream_t stream, bool qk16 = false) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.part_f16 = !x3;
-    fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT; fp.nQG = g.nQG;
+    fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT;
+    fp.nQG = g.nQG + (fp.rowmap ? kSkipPadGroups : 0);
     fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.nblk = nblk;
     for (int k = 0; k <= g.W; ++k) fp.bound[k] = g.bound[k];
     for (int b = 0; b < kBlocks; ++b) { fp.first_run[b] = g.first_run[b]; fp.nseg[b] = g.nseg[b]; }
@@ -463,8 +570,8 @@ extern "C" size_t sid_injected_attn_workspace_bytes(int B, int H, int N, int d, 
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
     const bool x3 = compute == SID_COMPUTE_F32X3;
     size_t bytes = 0;
-    for (int thr = 0; thr < 2; ++thr) {          // enough for either decomposition (SID_FLAG_THROUGHPUT)
-        if (make_geometry(B, H, N, N, d, kBlocks, x3, thr != 0, &g) != SID_OK) return 0;
+    for (int v = 0; v < 4; ++v) {                // enough for any decomposition (SID_FLAG_THROUGHPUT, SID_FLAG_BLOCK_SKIP)
+        if (make_geometry(B, H, N, N, d, kBlocks, x3, (v & 1) != 0, &g, (v & 2) != 0) != SID_OK) return 0;
         Workspace w;
         carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w);
         bytes = std::max(bytes, w.bytes);
@@ -498,6 +605,24 @@ int static_scratch(void** ptr) {
     return SID_OK;
 }
 
+// SID_FLAG_BLOCK_SKIP takes effect where its bounds hold and where it can pay: positive logit scales (the
+// bounds are monotone only then), the f32 row statistics of the bf16 / f16 kernels, and key blocks of at
+// least 2048 keys (below that the bounds cost more than the stages they can save).
+bool skip_applies(int flags, int compute, int N, int d, float T, float scale) {
+    return (flags & SID_FLAG_BLOCK_SKIP) && compute != SID_COMPUTE_F32X3 && T > 0.f && scale > 0.f && N >= 2048 &&
+           T * scale * LOG2E >= 0x1p-30f && scale * LOG2E >= 0x1p-30f;
+}
+// Margin in log2 units: a block of N keys, every logit `gap` below the row's largest, weighs at most
+// N * 2^-gap of the row sum; kDeadGapBase keeps that under half an ulp of f32 with a factor 4 to spare.
+// SID_TUNE_DEAD_GAP overrides it (tests: a huge value drops nothing with the same decomposition).
+float dead_gap(int N) {
+    if (const char* e = getenv("SID_TUNE_DEAD_GAP")) {
+        const float v = (float)atof(e);
+        if (v > 0.f) return v;
+    }
+    return kDeadGapBase + std::ceil(std::log2((float)N));
+}
+
 int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
                        const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
                        const float* mask_signed, void* out, int B, int H, int N, int d,
@@ -520,7 +645,10 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
                   "gamma, q_self_coef, T and scale must be finite");
     const bool x3 = compute == SID_COMPUTE_F32X3;
     Geometry g;
-    rc = make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
+    // block skipping needs positive logit scales (the bounds are monotone only then), the f32 row statistics
+    // of the bf16 / f16 kernels, and 64 real keys to sample
+    const bool skip = skip_applies(flags, compute, N, d, T, scale);
+    rc = make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g, skip);
     if (rc != SID_OK) return rc;
     Workspace w;
     carve(g, kBlocks, 2, x3, (long long)B * H * N, d, workspace, &w, kv_images == nullptr);
@@ -568,6 +696,10 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
         set_strides(pp.job[0], SID_LAYOUT_BNHD, H, N, d, true);
         rowjob(1, q_cnt, w.q[1][0], w.q[1][1], g.NQT, g.q_units);      // content query
         pp.job[1].post = c2c;
+        if (skip) {
+            pp.rm_mask = mask_signed; pp.rm_out = w.rowmap; pp.rm_groups = w.rowmap_groups; pp.rm_counters = w.skip_count;
+            pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32; pp.rm_ts = T * scale;
+        }
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};
         for (int b = 0; b < kBlocks && !kv_images; ++b) {
@@ -576,7 +708,7 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
             rowjob(5 + b, vs[b], w.v[b][0], w.v[b][1], g.NKT, g.v_units);
             pp.job[5 + b].kind = 1;
         }
-        rc = launch_pack(pp, frags, stream);
+        rc = launch_pack(pp, frags, stream, skip ? B : 0);
         if (rc != SID_OK) return rc;
     }
     // ---- flash
@@ -590,6 +722,18 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
     }
     fp.c2[0] = fp.c2[1] = c2s;
     fp.c2[2] = c2c;
+    if (skip) {
+        if (g.bound2[g.W] != 2 * g.SPB) return sid::fail(SID_EINVAL, "internal: no two-block run table for W=%d SPB=%d", g.W, g.SPB);
+        fp.rowmap = w.rowmap; fp.rowmap_groups = w.rowmap_groups; fp.mask = mask_signed; fp.skip_count = w.skip_count;
+        fp.NP = (int)skip_positions(g);
+        const int full_tiles = N / 32;                      // key tiles without padding
+        fp.nsamp = std::min(kProbeTiles, full_tiles);
+        fp.samp_stride = full_tiles / fp.nsamp;
+        fp.ts = T * scale;
+        fp.dead_gap = dead_gap(N);
+        for (int k = 0; k <= g.W; ++k) fp.bound2[k] = g.bound2[k];
+        for (int b = 0; b < 2; ++b) { fp.first_run2[b] = g.first_run2[b]; fp.nseg2[b] = g.nseg2[b]; }
+    }
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream, qk16);
 }
 
@@ -666,8 +810,8 @@ extern "C" size_t sid_injected_attn_packed_workspace_bytes(int B, int H, int N, 
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
     const bool x3 = compute == SID_COMPUTE_F32X3;
     size_t bytes = 0;
-    for (int thr = 0; thr < 2; ++thr) {
-        if (make_geometry(B, H, N, N, d, kBlocks, x3, thr != 0, &g) != SID_OK) return 0;
+    for (int v = 0; v < 4; ++v) {
+        if (make_geometry(B, H, N, N, d, kBlocks, x3, (v & 1) != 0, &g, (v & 2) != 0) != SID_OK) return 0;
         Workspace w;
         carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w, false);
         bytes = std::max(bytes, w.bytes);
@@ -685,6 +829,17 @@ extern "C" int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt, 
     return injected_attn_impl(x_q, q_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mask_signed, out, B, H, N, d,
                               gamma, q_self_coef, T, scale, dtype, compute, flags, workspace, workspace_bytes, false,
                               (hipStream_t)stream, images);
+}
+
+extern "C" long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int compute, int flags, int packed) {
+    Geometry g;
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return -1;
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    if (!skip_applies(flags, compute, N, d, 1.f, 1.f)) return -1;
+    if (make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g, true) != SID_OK) return -1;
+    Workspace w;
+    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w, packed == 0);
+    return (long long)w.skip_count_off;
 }
 
 extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]) {

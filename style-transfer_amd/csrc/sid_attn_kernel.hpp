@@ -64,6 +64,25 @@ struct FlashParams {
     unsigned short bound[kMaxRuns + 1];   // run w covers stages [bound[w], bound[w + 1]) of that sequence
     unsigned char first_run[kBlocks];     // the run that holds a block's first stage
     unsigned char nseg[kBlocks];          // runs that overlap a block = partial slots it uses (<= KS)
+    // SID_FLAG_BLOCK_SKIP (rowmap null: off; served by the SKIP kernel instances).  The queries of an image
+    // are regrouped by mask side: position i of image b holds token rowmap[b * NP + i] (-1: padding; every
+    // side starts on a workgroup boundary, so no workgroup straddles two sides), rowmap_groups[b] query
+    // groups are in use (nQG counts the launch's groups: up to two more than the tokens need).  Every
+    // workgroup bounds the logits of its rows from nsamp sampled key tiles per block (tiles j * samp_stride)
+    // and drops what the bounds prove dead (margin dead_gap, see kDeadGapBase; ts = T * scale).  A group
+    // with a dead style block runs the two remaining blocks as ONE sequence of 2 * SPB stages cut by
+    // bound2 (first_run2 / nseg2 indexed by position in that sequence).
+    // skip_count[0..3] = query groups with a dead style block / content segments reduced to their logits /
+    // such segments redone in full / query groups
+    const int* rowmap;
+    const int* rowmap_groups;
+    const float* mask;           // (B, Nq) signed mask, by token
+    unsigned* skip_count;
+    int NP;
+    int nsamp, samp_stride;
+    float ts, dead_gap;
+    unsigned short bound2[kMaxRuns + 1];
+    unsigned char first_run2[2], nseg2[2];
     int nblk;                    // 3: injected [char | back | content], 1: single block
     int direct;                  // single part: normalise and write `out` here, no merge kernel
     int out_bf16;
@@ -95,6 +114,8 @@ struct Geometry {
     int W, G;          // runs per (head, query group) over the nblk * SPB stages; stages of the longest run
     unsigned short bound[kMaxRuns + 1];
     unsigned char first_run[kBlocks], nseg[kBlocks];
+    unsigned short bound2[kMaxRuns + 1];          // block skipping: the same W runs over two blocks
+    unsigned char first_run2[2], nseg2[2];
     int NQT, NKT;      // tiles in the packed images
     int nQG;
     size_t lds;
@@ -127,6 +148,17 @@ constexpr bool pipelined(int DKS, int DVB, bool x3) {
 #define SID_RING 2
 #endif
 constexpr int ring_stages(int DKS, int DVB, bool x3) { return SID_RING; }
+// Block-skipping instances: the logits-only pass over a content block stages key tiles alone, through a
+// deeper ring (it has little arithmetic per stage to hide the copy behind): up to 8 stages in up to 64 KiB.
+constexpr int skip_ring(int DKS, int DVB, bool x3) {
+    const int per_stage = stage_tiles(DKS, DVB, x3) * DKS * 1024;
+    return 64 * 1024 / per_stage < 8 ? 64 * 1024 / per_stage : 8;
+}
+constexpr size_t skip_lds_bytes(int DKS, int DVB, bool x3) {
+    const size_t normal = (size_t)ring_stages(DKS, DVB, x3) * stage_tiles(DKS, DVB, x3) * tile_bytes(DKS, DVB, x3);
+    const size_t ring = (size_t)skip_ring(DKS, DVB, x3) * stage_tiles(DKS, DVB, x3) * DKS * 1024;
+    return ring > normal ? ring : normal;
+}
 
 int launch_flash_bf16(const FlashParams& fp, const Geometry& g, hipStream_t stream);
 int launch_flash_x3(const FlashParams& fp, const Geometry& g, hipStream_t stream);
@@ -168,6 +200,13 @@ struct RowState {
 //             the query fragments hold -m2 as a bf16 pair and the key image holds ones there, so the
 //             accumulator is x - m2 and p = exp2(S) with no VALU arithmetic in front of the exponential
 enum { kOnline = 0, kFixed = 1, kShifted = 2 };
+
+// Block skipping (SID_FLAG_BLOCK_SKIP): a key block may be left out for a query row when its whole
+// softmax mass is below half an ulp of the f32 row sum, i.e. when the largest biased logit it can hold
+// lies more than kDeadGapBase + log2(keys of the block) log2 units under a logit the row is known to hold.
+constexpr float kDeadGapBase = 26.f;
+constexpr int kProbeTiles = 4;        // key tiles (of 32 keys) sampled per block for the bounds
+constexpr int kSkipPadGroups = 2;     // query groups a launch adds for the padding between mask sides
 
 __device__ __forceinline__ float max16(const f32x16& S) {
     float t = fmaxf(fmaxf(S[0], S[1]), S[2]);
@@ -511,8 +550,11 @@ __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vm
 // SHIFT: the kShifted steady state (head_dim % 16 == 8); a separate instance rather than a run-time
 // branch, because a kernel that carries both steady-state loops no longer fits its registers.
 // QK16: half-precision (f16) query and key images (SID_COMPUTE_F16QK); see mfma_qk.
-template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT, bool QK16>
+// SKIP: block skipping (SID_FLAG_BLOCK_SKIP); instances of their own, so that calls without the flag run
+// exactly the code they ran before it existed.
+template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT, bool QK16, bool SKIP = false>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashParams P) {
+    static_assert(!(SKIP && X3), "block skipping reads the f32 statistics of the bf16 / f16 kernels");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     constexpr int KU = KVS * DKS * 64;        // u32x4 per stage: K image
     constexpr int VU = KVS * 2 * DVB * 64;    //                  V image
@@ -546,7 +588,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     // equal mod 8 when the group count allows, i.e. they share an XCD and its L2 (speed only)
     const int groups = BH * P.W;
     int grp, qg;
-    {
+    if constexpr (SKIP) {
+        // run-major: the runs over the style blocks, which are never shortened, start before the runs over
+        // the content block; heads alternate fastest (the workgroups of a head share an XCD when BH % 8 == 0)
+        const int id = blockIdx.x, per_run = BH * P.nQG;
+        const int rest = id % per_run;
+        grp = (rest % BH) * P.W + id / per_run;
+        qg = rest / BH;
+    } else {
         const int id = blockIdx.x;
         if ((groups & 7) == 0) {
             const int slot = id >> 3;
@@ -562,11 +611,117 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     // block costs).  Where a run crosses a block boundary the workgroup finishes one segment (its own
     // partial output and statistics) and starts the next.
     const int run_w = grp % P.W, bh = grp / P.W;
-    const int g0 = P.bound[run_w], g1 = P.bound[run_w + 1];
 
     // this wave's query tiles; surplus tiles redo the last one and store nothing
     const int qt0 = (qg * NW + wave) * QT;
+    // SKIP: the token behind each of this lane's query rows (-1: padding)
+    int tok[SKIP ? QT : 1];
+    if constexpr (SKIP) {
+        const int b_ = bh / P.H;
+        if (qg >= P.rowmap_groups[b_]) return;            // the whole workgroup: a padding group of the launch
+#pragma unroll
+        for (int t = 0; t < QT; ++t) tok[t] = P.rowmap[(size_t)b_ * P.NP + (qt0 + t) * 32 + (lane & 31)];
+    }
+    // token of this lane's row of query tile t, -1 where there is nothing to store
+    auto row_token = [&](int t) {
+        if constexpr (SKIP) {
+            return tok[t];
+        } else {
+            const int qt = qt0 + t;
+            const int q = qt * 32 + (lane & 31);
+            return (qt >= P.NQT || q >= P.Nq) ? -1 : q;
+        }
+    };
+    // this lane's part of the fragments of query tile t in a packed query image
+    auto q_frag_ptr = [&](const u32x4* image, int t) {
+        if constexpr (SKIP) {
+            const int tc = max(tok[t], 0);                // padding rows compute on token 0 and store nothing
+            return image + ((size_t)(bh * P.NQT + (tc >> 5)) * DKS) * 64 + hh * 32 + (tc & 31);
+        } else {
+            return image + ((size_t)(bh * P.NQT + min(qt0 + t, P.NQT - 1)) * DKS) * 64 + lane;
+        }
+    };
     Frags<DKS, X3> qf[QT];
+
+    // ---- block skipping: bounds from sampled keys, one decision for the whole workgroup.  In log2 units,
+    // with x the packed-image logits (style: T*s*log2e * q.k, content: s*log2e * q_cnt.k_cnt), ts = T*s:
+    //     style block b, key j :  x_bj + (min_j xc - max_j x_b / ts) * (m * ch_b),   ch_1 = -1, ch_2 = +1
+    //     content, key j       :  xc_j
+    // For a row with m > ts > 0 (mirrored for m < -ts), from ANY sampled keys:
+    //     the row holds a logit >= LB  = x1 + (x1 / ts - xc) * m         (x1: a block-1 sample, xc: a content sample)
+    //     every logit of block 2 <= UB2 = x2 * (1 - m / ts) + m * xc      (x2: a block-2 sample)
+    // because the true max_j x_b is at least any sample and the true min_j xc at most any sample, and both
+    // bounds are monotone in those.  Block 2 is dead for the row when LB - UB2 >= dead_gap.  The content
+    // block's maximum is not bounded by samples: it is only PREDICTED dead here and verified below with
+    // the exact maximum of its segment.  The workgroups of one query group read the same samples with the
+    // same instructions, so they agree.
+    int dead = -1;
+    unsigned gflags = 0;
+    float row_lb[SKIP ? QT : 1];
+    if constexpr (SKIP) {
+        Frags<DKS, false> qb[QT], qc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            qb[t].load(q_frag_ptr(P.q[0], t), 0);
+            qc[t].load(q_frag_ptr(P.q[kBlocks - 1], t), 0);
+        }
+        float xs[kBlocks][QT], cmn[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) cmn[t] = SID_INF;
+#pragma unroll
+        for (int b = 0; b < kBlocks; ++b) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) xs[b][t] = -SID_INF;
+            // a fixed trip count with a clamped index (a repeated tile changes no extreme): the loads do not
+            // depend on each other, so as many are in flight as registers allow
+#pragma unroll
+            for (int j = 0; j < kProbeTiles; ++j) {
+                Frags<DKS, false> kf;
+                kf.load(P.k[b] + ((size_t)(bh * P.NKT + min(j, P.nsamp - 1) * P.samp_stride) * DKS) * 64 + lane, 0);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const f32x16 S = qk_tile<DKS, false, QK16>(kf, b == kBlocks - 1 ? qc[t] : qb[t]);
+                    xs[b][t] = fmaxf(xs[b][t], max16(S));
+                    if (b == kBlocks - 1) cmn[t] = fminf(cmn[t], min16(S));
+                }
+            }
+        }
+        unsigned bad = 0;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float x[kBlocks];
+#pragma unroll
+            for (int b = 0; b < kBlocks; ++b) x[b] = fmaxf(xs[b][t], __shfl_xor(xs[b][t], 32));
+            const float cmin = fminf(cmn[t], __shfl_xor(cmn[t], 32)), cmax = x[kBlocks - 1];
+            row_lb[t] = -SID_INF;
+            if (tok[t] >= 0) {                            // padding rows agree with everything
+                const float m = P.mask[(size_t)(bh / P.H) * P.Nq + tok[t]];
+                const float am = fabsf(m);
+                bool d1 = false, d2 = false, dc = false;
+                if (am > P.ts) {
+                    const float xl = m > 0.f ? x[0] : x[1], xd = m > 0.f ? x[1] : x[0];
+                    const float lbv = xl + (xl / P.ts - cmin) * am;
+                    const float ub = xd * (1.f - am / P.ts) + am * cmin;
+                    const bool far_dead = lbv - ub >= P.dead_gap;
+                    d1 = far_dead && m < 0.f;
+                    d2 = far_dead && m > 0.f;
+                    // a guess with half the sampled range of headroom
+                    dc = lbv - (cmax + 0.5f * (cmax - cmin)) >= P.dead_gap;
+                    row_lb[t] = lbv;
+                }
+                bad |= (d1 ? 0u : 1u) | (d2 ? 0u : 2u) | (dc ? 0u : 4u);
+            }
+        }
+        gflags = 0;                                       // (the workgroup votes are boolean: one per bit)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            gflags |= __builtin_amdgcn_readfirstlane(__syncthreads_and((int)((bad >> k) & 1u) == 0)) ? 1u << k : 0u;
+        if ((gflags & 3u) == 3u) gflags &= ~3u;           // (only a group of padding alone could say so)
+        dead = (gflags & 3u) == 1u ? 0 : ((gflags & 3u) == 2u ? 1 : -1);
+    }
+    const int g0 = dead >= 0 ? P.bound2[run_w] : P.bound[run_w];
+    const int g1 = dead >= 0 ? P.bound2[run_w + 1] : P.bound[run_w + 1];
+    auto real_block = [&](int tb) { return dead < 0 ? tb : (tb == 0 ? 1 - dead : kBlocks - 1); };
 
     // per segment: block, first stage and stage count within the block, partial slot, scale, images
     int blk = 0, st0 = 0, slen = 0, part = 0;
@@ -708,23 +863,139 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         gvl = X3 ? P.v_lo[b_] + (size_t)bh * P.NKT * 2 * DVB * 64 : nullptr;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const int qt = min(qt0 + t, P.NQT - 1);
-            qf[t].load(P.q[b_] + ((size_t)(bh * P.NQT + qt) * DKS) * 64 + lane,
-                       X3 ? (int)(P.q_lo[b_] - P.q[b_]) : 0);
+            qf[t].load(q_frag_ptr(P.q[b_], t), X3 ? (int)(P.q_lo[b_] - P.q[b_]) : 0);
         }
     };
     // A segment that is followed by another one requests that segment's first stages and query
     // fragments before it stores its own results, so their latency passes behind the store.
     int prefetched = 0;               // stages of the segment about to start that are already issued
 
-    for (blk = g0 / P.SPB; blk * P.SPB < g1; ++blk) {
-    st0 = max(g0 - blk * P.SPB, 0);
-    slen = min(g1 - blk * P.SPB, P.SPB) - st0;
-    const int first_run = P.first_run[blk];                  // the run that holds the block's first stage
+    unsigned skipc = 0;               // block-skipping counters of this workgroup, one per byte (<= 3 segments)
+    if constexpr (SKIP) {
+        if (run_w == 0) skipc = (1u << 24) | (dead >= 0 ? 1u : 0u);
+        if (dead >= 0 && run_w == 0) {
+            // nobody computes the dead block: its partial slots are marked empty here
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int q = row_token(t);
+                if (q < 0 || hh != 0) continue;
+                for (int pp = 0; pp < P.KS; ++pp) {
+                    f32x4 none = {-SID_INF, 0.f, -SID_INF, SID_INF};
+                    *(f32x4*)(P.stats + ((((size_t)dead * P.KS + pp) * BH + bh) * P.Nq + q) * 4) = none;
+                }
+            }
+        }
+    }
+
+    for (int tb = g0 / P.SPB; tb * P.SPB < g1; ++tb) {
+    blk = real_block(tb);
+    st0 = max(g0 - tb * P.SPB, 0);
+    slen = min(g1 - tb * P.SPB, P.SPB) - st0;
+    const int first_run = dead >= 0 ? P.first_run2[tb] : P.first_run[tb];   // the run that holds the block's first stage
+    const int nseg_blk = dead >= 0 ? P.nseg2[tb] : P.nseg[tb];
     part = blk * P.KS + (run_w - first_run);
     if (!prefetched) enter_block(blk);
     c2 = P.c2[blk];
     need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || c2 < 0.f;
+
+    // ---- block skipping, content block predicted dead for the whole query group: only the extremes of
+    // its logits are needed (the mask bias takes min cc exactly), then the exact segment maximum is checked
+    // against every row's bound.  Only the key images are staged, through a ring of as many key-only
+    // buffers as the LDS of the normal stages holds, one barrier per stage.
+    if constexpr (SKIP) if ((gflags & 4u) && blk == kBlocks - 1) {
+        // The copy runs in chunks of CH stages (one barrier per chunk) through a ring of RC chunk buffers,
+        // RC - 1 chunks ahead.
+        constexpr int CH = skip_ring(DKS, DVB, X3) >= 6 ? 2 : 1, RC = skip_ring(DKS, DVB, X3) / CH;
+        constexpr int CU = CH * KUn;                  // 1 KiB units per chunk
+        constexpr int NLC = (CU + NW - 1) / NW;       // direct loads per wave and chunk
+        static_assert(RC >= 3 && (size_t)RC * CH * KU * 16 <= skip_lds_bytes(DKS, DVB, X3), "logits-only ring");
+        wait_direct_loads();          // stages the previous segment requested ahead: let them land, unused
+        prefetched = 0;
+        __syncthreads();
+        const int nchunk = (slen + CH - 1) / CH;
+        const int last_unit = slen * KUn - 1;         // (units past the segment repeat its last one, unread)
+        auto issue_chunk = [&](int c, int buf) {
+            const unsigned dk = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * CH * KU) * 16);
+            static_for<0, NLC>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const int u = (CU % NW == 0 || (i + 1) * NW <= CU) ? wave + i * NW : min(wave + i * NW, CU - 1);
+                glds16(gk + (size_t)st0 * KU + (size_t)min(c * CU + u, last_unit) * 64, lane_bytes, dk + u * 1024);
+            });
+        };
+        float lmax[QT], lmin[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { lmax[t] = -SID_INF; lmin[t] = SID_INF; }
+        const int nfull_ = max(0, min(slen, P.Nk / (KVS * 32) - st0));
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): nothing the compiler counts is outstanding
+        // chunks past the end repeat the last one (into a free buffer, unread): every iteration issues the
+        // same number of loads, so "chunk c has landed" is a constant count of younger loads
+        for (int k = 0; k < RC - 1; ++k) issue_chunk(min(k, nchunk - 1), k);
+        for (int c = 0; c < nchunk; ++c) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RC - 2) * NLC) : "memory");
+            __syncthreads();          // chunk c is visible; every wave is done with chunk c - 1
+            issue_chunk(min(c + RC - 1, nchunk - 1), (c + RC - 1) % RC);
+            const u32x4* L = lds + (c % RC) * CH * KU;
+            if (c * CH + CH <= nfull_) {
+#pragma unroll
+                for (int j = 0; j < CH * KVS; ++j) {
+                    Frags<DKS, X3> kf;
+                    kf.load(L + (j * DKS) * 64 + lane, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const f32x16 S = qk_tile<DKS, X3, QK16>(kf, qf[t]);
+                        lmax[t] = fmaxf(lmax[t], max16(S));
+                        lmin[t] = fminf(lmin[t], min16(S));
+                    }
+                }
+            } else {                              // the chunk holds padding keys or ends the segment early
+                for (int j = 0; j < CH * KVS; ++j) {
+                    if (c * CH + j / KVS >= slen) break;
+                    Frags<DKS, X3> kf;
+                    kf.load(L + (j * DKS) * 64 + lane, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const f32x16 S = qk_tile<DKS, X3, QK16>(kf, qf[t]);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const bool valid = ((st0 + c * CH) * KVS + j) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh < P.Nk;
+                            lmax[t] = valid ? fmaxf(lmax[t], S[i]) : lmax[t];
+                            lmin[t] = valid ? fminf(lmin[t], S[i]) : lmin[t];
+                        }
+                    }
+                }
+            }
+        }
+        wait_direct_loads();
+        bool ok = true;
+        float xmax[QT], xmin[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            xmax[t] = fmaxf(lmax[t], __shfl_xor(lmax[t], 32));
+            xmin[t] = fminf(lmin[t], __shfl_xor(lmin[t], 32));
+            if (row_token(t) >= 0) ok &= xmax[t] <= row_lb[t] - P.dead_gap;
+        }
+        skipc += 1u << 8;
+        // (the barrier inside also keeps a redo from refilling LDS under a wave that still reads it)
+        if (__builtin_amdgcn_readfirstlane(__syncthreads_and((int)ok))) {
+            // statistics of a slot that weighs nothing but still reports its logit extremes
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int q = row_token(t);
+                if (q < 0 || hh != 0) continue;
+                const float inv_c2 = 1.0f / c2;           // c2 > 0 whenever skipping is on
+                f32x4 st = {-SID_INF, 0.f, xmax[t] * inv_c2, xmin[t] * inv_c2};
+                *(f32x4*)(P.stats + (((size_t)part * BH + bh) * P.Nq + q) * 4) = st;
+                if (run_w == first_run) {
+                    for (int pp = nseg_blk; pp < P.KS; ++pp) {
+                        f32x4 none = {-SID_INF, 0.f, -SID_INF, SID_INF};
+                        *(f32x4*)(P.stats + ((((size_t)blk * P.KS + pp) * BH + bh) * P.Nq + q) * 4) = none;
+                    }
+                }
+            }
+            continue;
+        }
+        skipc += 1u << 16;            // the prediction failed: the segment runs in full
+    }
     if (tid == 0) redo = 0;           // published by the barrier of the prologue below
 
     // stages of this segment that hold only valid keys (the rest are tails)
@@ -837,9 +1108,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     }
     // every wave is past its last LDS read of this segment: start the next segment (it begins at
     // stage 0 of the next block); nothing below touches LDS, the images or the query fragments
-    if ((blk + 1) * P.SPB < g1) {
-        enter_block(blk + 1);
-        prefetched = min(NB, min(g1 - (blk + 1) * P.SPB, P.SPB));
+    if ((tb + 1) * P.SPB < g1) {
+        enter_block(real_block(tb + 1));
+        prefetched = min(NB, min(g1 - (tb + 1) * P.SPB, P.SPB));
         for (int k = 0; k < prefetched; ++k) issue_stage(k, k);
     }
 
@@ -857,9 +1128,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         // softmax denominator = the ones column = row 31 of the last dv block = register 15, half 1
         float lsum = hh ? O[t][DVB - 1][15] : 0.f;
         lsum += __shfl_xor(lsum, 32);
-        const int qt = qt0 + t;
-        const int q = qt * 32 + (lane & 31);
-        if (qt >= P.NQT || q >= P.Nq) continue;
+        const int q = row_token(t);
+        if (q < 0) continue;
         if (P.direct) {
             const float inv = 1.0f / lsum;
             const int b_ = bh / P.H, h_ = bh % P.H;
@@ -934,7 +1204,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 // a block cut into fewer segments than there are partial slots per block: the first
                 // segment marks the unused slots empty (sum 0; the merge skips them)
                 if (run_w == first_run) {
-                    for (int pp = P.nseg[blk]; pp < P.KS; ++pp) {
+                    for (int pp = nseg_blk; pp < P.KS; ++pp) {
                         f32x4 none = {-SID_INF, 0.f, -SID_INF, SID_INF};
                         *(f32x4*)(P.stats + ((((size_t)blk * P.KS + pp) * BH + bh) * P.Nq + q) * 4) = none;
                     }
@@ -949,26 +1219,40 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
 #endif
     }   // segments
     wait_direct_loads();      // the pipelined loop leaves (redundant) stage copies in flight
+    if (SKIP && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((skipc >> (8 * i)) & 255u) atomicAdd(P.skip_count + i, (skipc >> (8 * i)) & 255u);
+    }
 }
 
-template <int DKS, int DVB, bool X3, int NW, bool SHIFT, bool QK16>
+template <int DKS, int DVB, bool X3, int NW, bool SHIFT, bool QK16, bool SKIP = false>
 int launch_flash_inst(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
     constexpr int KVS = stage_tiles(DKS, DVB, X3);
     constexpr int QT = query_tiles(DKS, DVB, X3);
-    constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT, QK16>;
-    constexpr size_t lds_need = (size_t)ring_stages(DKS, DVB, X3) * KVS * tile_bytes(DKS, DVB, X3);
+    constexpr auto kern = flash_kernel<DKS, DVB, KVS, X3, QT, NW, SHIFT, QK16, SKIP>;
+    constexpr size_t lds_need = SKIP ? skip_lds_bytes(DKS, DVB, X3)
+                                     : (size_t)ring_stages(DKS, DVB, X3) * KVS * tile_bytes(DKS, DVB, X3);
     if (lds_need > 48 * 1024) {
         const int rc = sid::allow_dynamic_lds<kern>(lds_need);
         if (rc != SID_OK) return rc;
     }
-    const long long grid = (long long)g.nQG * fp.B * fp.H * fp.W;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), g.lds, stream, fp);
+    const long long grid = (long long)fp.nQG * fp.B * fp.H * fp.W;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), SKIP ? lds_need : g.lds, stream, fp);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
 }
 
 template <int DKS, int DVB, bool X3, bool SHIFT, bool QK16>
 int launch_flash_nw(const FlashParams& fp, const Geometry& g, hipStream_t stream) {
+    if constexpr (!X3) {
+        // block skipping is only on for long key blocks, whose calls take workgroups of 8 or 4 waves
+        if (fp.rowmap) {
+            if (g.NW == 8) return launch_flash_inst<DKS, DVB, X3, 8, SHIFT, QK16, true>(fp, g, stream);
+            if (g.NW == 4) return launch_flash_inst<DKS, DVB, X3, 4, SHIFT, QK16, true>(fp, g, stream);
+            return sid::fail(SID_EINVAL, "internal: block skipping with %d waves per workgroup", g.NW);
+        }
+    }
     switch (g.NW) {
         case 8: return launch_flash_inst<DKS, DVB, X3, 8, SHIFT, QK16>(fp, g, stream);
         case 4: return launch_flash_inst<DKS, DVB, X3, 4, SHIFT, QK16>(fp, g, stream);

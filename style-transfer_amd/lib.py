@@ -29,6 +29,7 @@ SIGNATURES = {
     "sid_pack_kv": (_i, [_vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "sid_injected_attn_packed_workspace_bytes": (_sz, [_i] * 5),
     "sid_injected_attn_fwd_packed": (_i, [_vp] * 5 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sid_injected_attn_skip_counts_offset": (_c.c_longlong, [_i] * 7),
     "sid_attn_plan": (_i, [_i] * 8 + [_c.POINTER(_c.c_int)]),
     "sid_plain_attn_workspace_bytes": (_sz, [_i] * 6),
     "sid_plain_attn_fwd": (_i, [_vp] * 4 + [_i] * 5 + [_f] + [_i] * 5 + [_vp, _sz, _vp]),
@@ -58,7 +59,11 @@ def load():
                 "(hipcc --offload-arch=gfx950); this package has no fallback path" % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                if os.environ.get("SID_LIB_OVERRIDE"):
+                    continue          # an older experimental build may predate an entry point
+                raise AttributeError("%s does not export %s" % (LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
         _lib = lib

@@ -110,6 +110,20 @@ def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, ga
 
 
 FLAG_THROUGHPUT = 2      # SID_FLAG_THROUGHPUT: the caller keeps the GPU busy with other streams
+FLAG_BLOCK_SKIP = 1      # SID_FLAG_BLOCK_SKIP: drop key blocks whose softmax mass is provably nil
+
+
+def skip_counts(x_q, heads, compute="bf16", flags=FLAG_BLOCK_SKIP, packed=False):
+    """The block-skipping counters of the last injected-attention call made on the current stream with this
+    shape: (segments dropped, content segments reduced to logits, of those redone in full, segments seen),
+    or None where the flag has no effect.  Synchronises."""
+    L = _lib.load()
+    B, N, C = x_q.shape
+    off = L.sid_injected_attn_skip_counts_offset(B, heads, N, C // heads, _compute_code(compute), int(flags), int(packed))
+    if off < 0:
+        return None
+    ws = _workspaces[(x_q.device.index, _stream(x_q.device))]
+    return tuple(int(v) for v in ws[off:off + 16].view(torch.int32).cpu())
 
 
 class PackedKV:

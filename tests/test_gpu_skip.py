@@ -1,0 +1,177 @@
+"""SID_FLAG_BLOCK_SKIP: key blocks whose softmax mass is provably below f32 rounding are left out for whole
+workgroups of queries (queries are regrouped so that workgroups mostly sit on one side of the mask).
+The flag must not change results beyond what a different cut of the key runs does, must actually drop
+work where logits are feature-sized, and must drop nothing it cannot prove."""
+import numpy as np
+import pytest
+import torch
+
+import sid_oracle as orc
+from helpers import rel_err
+from style_transfer_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+H = 8
+
+
+def inputs(seed, B, N, d, sigma, mask):
+    g = torch.Generator(device="cuda:0"); g.manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device="cuda:0", generator=g) * sigma
+    t = {"xq": rn(B, N, H * d)}
+    for k in ("q_cnt", "k1", "v1", "k2", "v2", "k_cnt", "v_cnt"):
+        t[k] = rn(B * H, N, d)
+    if mask == "halves":            # whole 256-query groups on one side
+        m = torch.ones(B, N, device="cuda:0"); m[:, N // 2:] = -1
+    elif mask == "disc":            # a region boundary that cuts through query groups
+        side = int(np.ceil(N ** 0.5))
+        m = torch.from_numpy(synth.disc_mask(side, 0.3).astype(np.float32).reshape(1, -1)[:, :N] * 2 - 1).to("cuda:0").repeat(B, 1)
+    elif mask == "random":
+        m = torch.sign(rn(B, N))
+    elif mask == "soft":            # |m| < T*scale on part of the rows: no bound there
+        m = torch.ones(B, N, device="cuda:0"); m[:, N // 2:] = -1
+        m[:, ::3] *= 0.05
+    t["mask"] = m.contiguous()
+    return t
+
+
+def run(t, d, compute, flags, T=1.5):
+    return ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"], t["mask"],
+                                  0.5, T, d ** -0.5, H, compute=compute, flags=flags)
+
+
+def oracle_rows(t, b, rows, d, T=1.5):
+    sl = slice(b * H, (b + 1) * H)
+    c = lambda x: x.cpu().numpy()
+    return orc.injected_attention_rows(rows, c(t["xq"][b]), c(t["q_cnt"][sl]), c(t["k1"][sl]), c(t["v1"][sl]), c(t["k2"][sl]),
+                                       c(t["v2"][sl]), c(t["k_cnt"][sl]), c(t["v_cnt"][sl]), c(t["mask"][b]), 0.5, T, d ** -0.5)
+
+
+def run_without_dropping(t, d, compute, monkeypatch):
+    """Same flag, same workgroup shape, but a margin nothing can meet."""
+    monkeypatch.setenv("SID_TUNE_DEAD_GAP", "1e30")
+    try:
+        return run(t, d, compute, ops.FLAG_BLOCK_SKIP), ops.skip_counts(t["xq"], H, compute)
+    finally:
+        monkeypatch.delenv("SID_TUNE_DEAD_GAP")
+
+
+# A query group that drops a block cuts the remaining key stages into different runs, and every run takes its
+# own softmax reference, so the probabilities round to bf16 differently: outputs move within the band of the
+# bf16 operand rounding (the same band two decompositions of an unflagged call differ by), normalised by the
+# largest output.  Dropping a block itself changes nothing f32 can see: test_dropped_blocks_weigh_nothing.
+SAME_BAND = 4e-3
+
+
+def block_mass_rows(t, b, rows, d, T=1.5):
+    """float64 softmax mass of [character block, background block, content block] for sampled rows: (H, R, 3)."""
+    sl = slice(b * H, (b + 1) * H)
+    c = lambda x: x.cpu().numpy().astype(np.float64)
+    qc = c(t["q_cnt"][sl])[:, rows]
+    q = qc * 0.5 + c(t["xq"][b])[rows].reshape(len(rows), H, d).transpose(1, 0, 2) * 0.5
+    s = d ** -0.5
+    mm = c(t["mask"][b])[rows].reshape(1, -1, 1)
+    cc = np.einsum("hid,hjd->hij", qc, c(t["k_cnt"][sl])) * s
+    r1 = np.einsum("hid,hjd->hij", q, c(t["k1"][sl]))
+    r2 = np.einsum("hid,hjd->hij", q, c(t["k2"][sl]))
+    mn = cc.min(-1, keepdims=True)
+    s1 = r1 * T * s + (mn - r1.max(-1, keepdims=True)) * (-mm)
+    s2 = r2 * T * s + (mn - r2.max(-1, keepdims=True)) * mm
+    top = np.maximum(np.maximum(s1.max(-1), s2.max(-1)), cc.max(-1))[..., None]
+    w = np.stack([np.exp(x - top).sum(-1) for x in (s1, s2, cc)], -1)
+    return w / w.sum(-1, keepdims=True)
+
+
+def test_dropped_blocks_weigh_nothing():
+    """Where the counters say that EVERY query group dropped its far style block and every content segment,
+    the float64 mass of those blocks must be below half an ulp of f32 on every sampled row."""
+    N, d = 4096, 40
+    t = inputs(7050, 1, N, d, 3.0, "halves")
+    out = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    assert dead == groups and redone == 0 and lo >= groups
+    rows = (synth.hash_u64(7051, 64) % np.uint64(N)).astype(np.int64)
+    mass = block_mass_rows(t, 0, rows, d)
+    far = np.where(rows < N // 2, mass[..., 1], mass[..., 0])      # m = +1 on the first half: block 2 is the far one
+    print("largest dropped mass: style %.2e, content %.2e" % (far.max(), mass[..., 2].max()))
+    assert far.max() < 2.0 ** -25 and mass[..., 2].max() < 2.0 ** -25
+    assert rel_err(out[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+@pytest.mark.parametrize("N,d,sigma,mask", [
+    (4096, 40, 3.0, "halves"), (4096, 40, 2.0, "halves"), (4096, 40, 3.0, "disc"), (2048, 80, 3.0, "halves"),
+    (4096, 40, 1.0, "halves"), (4096, 40, 1.0, "disc"), (4096, 40, 3.0, "random"), (4096, 40, 3.0, "soft"),
+    (4000, 40, 3.0, "halves"), (2500, 40, 3.0, "disc"),
+])
+def test_flag_changes_nothing_that_matters(N, d, sigma, mask, compute, monkeypatch):
+    t = inputs(7000 + N + int(sigma), 2, N, d, sigma, mask)
+    plain = run(t, d, compute, 0)
+    skipped = run(t, d, compute, ops.FLAG_BLOCK_SKIP)
+    counts = ops.skip_counts(t["xq"], H, compute)
+    kept, kept_counts = run_without_dropping(t, d, compute, monkeypatch)
+    scale = plain.abs().max().item()
+    diff = (kept - skipped).abs().max().item()
+    print("N=%d d=%d sigma=%.0f %s %s: groups with a dead block / content logits-only / redone / groups = %s, "
+          "max diff %.2e (vs flag off %.2e) of %.2e" % (N, d, sigma, mask, compute, counts, diff,
+                                                        (plain - skipped).abs().max().item(), scale))
+    assert torch.isfinite(skipped).all()
+    assert kept_counts[0] == 0 and kept_counts[1] == 0
+    assert diff <= SAME_BAND * scale
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * scale
+    dead, lo, redone, groups = counts
+    qt = 2 if d <= 48 else 1                             # 32-query tiles per wave
+    qwaves = -(-((N + 31) // 32) // qt)
+    nw = 8 if qwaves >= 64 else 4                        # waves per workgroup
+    base = 2 * H * -(-qwaves // nw)                      # every mask side starts a group of its own: up to two more
+    assert base <= groups <= base + 2 * H * 2 and dead <= groups and redone <= lo
+    if mask in ("halves", "disc", "random") and sigma >= 2.0:
+        assert dead == groups                            # no group straddles two sides of a binary mask
+    if mask == "soft" and sigma >= 2.0:
+        assert 0 < dead < groups                         # rows with |m| < T * scale have no bound
+    rows = (synth.hash_u64(7001, 10) % np.uint64(N)).astype(np.int64)
+    for b in (0, 1):
+        ref = oracle_rows(t, b, rows, d)
+        assert rel_err(skipped[b].cpu().numpy()[rows], ref) < (3.5e-2 if compute == "bf16" else 1e-2)
+
+
+def test_sampled_bounds_never_drop_a_block_that_matters():
+    """Adversarial for bounds taken from sampled keys: the dead-looking style block holds ONE key, not among
+    the samples, whose logit towers over everything (its bias is built from that maximum, so the block
+    only gets deader), and the content block holds one key far above the sampled ones for one query (the
+    workgroup's verification must catch it and run the segment in full)."""
+    N, d = 4096, 40
+    t = inputs(7100, 1, N, d, 3.0, "halves")
+    t["k2"][:, 2001] *= 6.0
+    t["k_cnt"][:, 3001] = t["q_cnt"][:, 100] * 4.0
+    plain = run(t, d, "bf16", 0)
+    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    counts = ops.skip_counts(t["xq"], H, "bf16")
+    print("adversarial: counts", counts)
+    assert counts[2] > 0                         # the towering content key was caught
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    rows = np.array([0, 100, 101, 255, 2047, 2048, 4095])
+    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+
+
+def test_flag_is_ignored_where_it_cannot_apply():
+    for N, d, compute, T in ((256, 40, "bf16", 1.5), (1024, 80, "bf16", 1.5), (4096, 40, "fp32", 1.5), (4096, 40, "bf16", -1.5)):
+        t = inputs(7200 + N, 1, N, d, 2.0, "halves")
+        a = run(t, d, compute, 0, T=T)
+        b = run(t, d, compute, ops.FLAG_BLOCK_SKIP, T=T)
+        assert torch.equal(a, b), (N, d, compute, T)
+    assert ops.skip_counts(t["xq"], H, "fp32") is None
+    assert ops.skip_counts(torch.empty(1, 1024, 640, device="cuda:0"), H, "bf16") is None
+
+
+def test_packed_entry_point_takes_the_flag():
+    N, d = 4096, 40
+    t = inputs(7300, 1, N, d, 3.0, "disc")
+    kv = [ops.pack_kv(t[k], t[v], H, "bf16") for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    plain = ops.injected_attention_packed(t["xq"], t["q_cnt"], *kv, t["mask"], 0.5, 1.5, d ** -0.5, H)
+    skipped = ops.injected_attention_packed(t["xq"], t["q_cnt"], *kv, t["mask"], 0.5, 1.5, d ** -0.5, H,
+                                            flags=ops.FLAG_BLOCK_SKIP)
+    counts = ops.skip_counts(t["xq"], H, "bf16", packed=True)
+    assert counts[0] > 0
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    unpacked = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    assert torch.equal(unpacked, skipped)

@@ -1,7 +1,7 @@
 """The injected attention call as a feature store serves it (key/value pairs pre-packed), timed the way the
 path runs it: a HIP graph of back-to-back calls.  Prints the whole call (query pack + flash + merge) and
 the flash stage alone.
-    python tools/prof_call.py [N d B reps compute flags]"""
+    python tools/prof_call.py [N d B reps compute flags sigma mask]      mask: random | halves | disc"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,11 +12,18 @@ base_flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 H = 8
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
-rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+sigma = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
+rn = lambda *s: torch.randn(*s, device=dev, generator=g) * sigma
 xq = rn(B, N, H * d)
 q_cnt = rn(B * H, N, d)
 kv = [ops.pack_kv(rn(B * H, N, d), rn(B * H, N, d), H, compute) for _ in range(3)]
 m = torch.sign(rn(B, N)).contiguous()
+if len(sys.argv) > 8 and sys.argv[8] == "halves":
+    m = torch.ones(B, N, device=dev); m[:, N // 2:] = -1
+if len(sys.argv) > 8 and sys.argv[8] == "disc":
+    from style_transfer_amd import synth
+    side = int(round(N ** 0.5))
+    m = (torch.from_numpy(synth.disc_mask(side, 0.3)).reshape(1, N) * 2 - 1).to(dev).repeat(B, 1).contiguous()
 out = torch.empty_like(xq)
 
 
@@ -46,5 +53,7 @@ def graph_time(fn):
 fl = 12.0 * B * H * N * N * d
 t_call = graph_time(call)
 t_flash = graph_time(lambda: call(0x20))
+if base_flags & 1:
+    call(); print("skip counters", ops.skip_counts(xq, H, compute, packed=True), end=" ")
 print("N=%d d=%d B=%d %s: call %.1f us (%.0f TF/s = %.1f%% of 2.5 PF) | flash stage alone %.1f us (%.1f%%)" % (
     N, d, B, compute, t_call, fl / t_call / 1e6, fl / t_call / 2.5e9 * 100, t_flash, fl / t_flash / 2.5e9 * 100))
