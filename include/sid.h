@@ -52,11 +52,22 @@ extern "C" {
 
 /* flags (bit mask) */
 /* Injected attention only: leave out a key block for a workgroup of queries when its whole softmax mass is
- * provably below half an ulp of the f32 row sums (bounds from sampled logits, 45 log2 units of margin;
- * the content block is predicted and then verified with its exact maximum, and still delivers min cc).
- * At feature-scale logits one style block is dead on every row with |mask| = 1.  Results change by less
- * than f32 rounding.  Takes effect with SID_COMPUTE_BF16 / F16QK, T > 0, scale > 0, N >= 64; elsewhere the
- * flag is ignored.  Workgroups then hold 256 queries. */
+ * provably below half an ulp of the f32 row sums.  The mask bias separates the two style blocks by
+ * 2 * |m| * (max q.k - min cc) / ... logits: at feature-sized logits the style block of the far mask side
+ * weighs nothing on every row with |mask| > T * scale, and often the content block does not either.
+ * With the flag the queries of an image are regrouped by mask side (workgroups then sit on one side
+ * whatever the shape of the region), every workgroup bounds its rows' logits from sampled key tiles and
+ *   - drops the far style block for all its rows when the bounds prove it dead (the two remaining
+ *     blocks are then cut into the same number of runs, each a third shorter);
+ *   - reduces a content block it predicts dead to a pass over its keys alone (the mask bias needs
+ *     min cc exactly) and verifies the prediction with the exact maximum, redoing the segment if wrong.
+ * Nothing is dropped on belief: results differ from the unflagged call only the way two decompositions of
+ * one call differ (runs round their probabilities to bf16 against their own reference).
+ * Takes effect with SID_COMPUTE_BF16 / F16QK, T > 0, scale > 0 and N >= 2048; elsewhere the flag is ignored.
+ * Measured on (1,8,4096,40), a disc mask: 25-40 % less time per call when the GPU is shared by 16 images,
+ * 7-10 % at one image, at logits of feature size (sigma 3); about 25 % MORE when no block can be dropped
+ * (the regrouping pads every mask side to a whole workgroup, and the bounds cost a few microseconds), so
+ * set it only for feature-sized logits.  sid_injected_attn_skip_counts_offset tells what was dropped. */
 #define SID_FLAG_BLOCK_SKIP 1
 /* The call shares the GPU with other work of the caller (other streams): choose the decomposition
  * with the least total work (no key-range splits, fewer partial results) instead of the one that

@@ -116,29 +116,41 @@ __device__ void rowmap_block(const PackParams& P, int b) {
     int* out = P.rm_out + (size_t)b * P.rm_NP;
     const float ts = P.rm_ts;
     auto cls = [&](float v) { return v > ts ? 0 : (v < -ts ? 2 : 1); };
-    // every thread owns a run of consecutive tokens, so positions inside a side keep the token order
-    const int per = (N + kThreads - 1) / kThreads;
-    const int r0 = min(N, tid * per), r1 = min(N, r0 + per);
-    int cnt[3] = {0, 0, 0};
-    for (int r = r0; r < r1; ++r) {
-        const int c = cls(m[r]);
+    // Every wave owns a run of consecutive tokens and walks it 64 at a time (coalesced loads that do not
+    // depend on each other, so many are in flight); a token's rank inside its side comes from the ballots.
+    // Positions inside a side keep the token order.
+    const int steps = (N + kThreads - 1) / kThreads;
+    const int w0 = wv * steps * 64;
+    constexpr int kBatch = 16;     // loads requested together
+    // side of the token `lane` of step s_ (-1 past the end), for kBatch steps at once
+    auto sides = [&](int s0, int (&c)[kBatch]) {
+        float v[kBatch];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) cnt[k] += c == k;
-    }
-    int before[3];                 // tokens of the side in lower threads of this wave
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        int v = cnt[k];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(v, off);
-            if (lane >= off) v += t;
+        for (int j = 0; j < kBatch; ++j) {
+            const int r = w0 + (s0 + j) * 64 + lane;
+            v[j] = m[min(r, N - 1)];
         }
-        before[k] = v - cnt[k];
-        if (lane == 63) wave_sum[k][wv] = v;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int r = w0 + (s0 + j) * 64 + lane;
+            c[j] = (s0 + j < steps && r < N) ? cls(v[j]) : -1;
+        }
+    };
+    int cnt[3] = {0, 0, 0};
+    for (int s0 = 0; s0 < steps; s0 += kBatch) {
+        int c[kBatch];
+        sides(s0, c);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cnt[k] += __popcll(__ballot(c[j] == k));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wave_sum[k][wv] = cnt[k];
     }
     __syncthreads();
-    int start = 0, first[3], total[3];
+    int start = 0, first[3], total[3], base[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int lower = 0;
@@ -150,14 +162,23 @@ __device__ void rowmap_block(const PackParams& P, int b) {
             total[k] += n;
         }
         first[k] = start;
-        before[k] += start + lower;
+        base[k] = start + lower;
         start += (total[k] + GR - 1) / GR * GR;
     }
-    for (int r = r0; r < r1; ++r) {
-        const int c = cls(m[r]);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int s0 = 0; s0 < steps; s0 += kBatch) {
+        int c[kBatch];
+        sides(s0, c);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (c == k) out[before[k]++] = r;
+        for (int j = 0; j < kBatch; ++j) {
+            const int r = w0 + (s0 + j) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long mk = __ballot(c[j] == k);
+                if (c[j] == k) out[base[k] + __popcll(mk & below)] = r;
+                base[k] += __popcll(mk);
+            }
+        }
     }
     for (int p = tid; p < P.rm_NP; p += kThreads) {
         bool gap = p >= start;
@@ -361,7 +382,10 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
             const int G_ = (T + w - 1) / w;
             if (G_ < std::min(16, stages)) break;
             const long long rounds = (pairs * w + slots - 1) / slots;
-            const double cost = (double)rounds * (G_ + 4) + 2.0 * slots_per_block(G_);
+            // (with block skipping the runs also cut two-block sequences, which raises the slots per block:
+            // there the slot term follows the rows the merge reads, 4096 x 8 being the calibration point)
+            const double slot_cost = skip ? 2.0 * std::max(1.0, (double)(BH * Nq) / 32768.0) : 2.0;
+            const double cost = (double)rounds * (G_ + 4) + slot_cost * slots_per_block(G_);
             if (cost < best - 1e-9) { best = cost; W = w; }
         }
     }
@@ -851,7 +875,8 @@ extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, in
     for (int i = 0; i < 40; ++i) plan[i] = 0;
     if (blocks == 1 && use_small_path(Nk, d)) return SID_OK;
     Geometry g;
-    rc = make_geometry(B, H, Nq, Nk, d, blocks, compute == SID_COMPUTE_F32X3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
+    rc = make_geometry(B, H, Nq, Nk, d, blocks, compute == SID_COMPUTE_F32X3, (flags & SID_FLAG_THROUGHPUT) != 0, &g,
+                       blocks == kBlocks && skip_applies(flags, compute, Nq, d, 1.f, 1.f));
     if (rc != SID_OK) return rc;
     plan[0] = g.W; plan[1] = g.G; plan[2] = g.SPB; plan[3] = g.KS; plan[4] = g.NW; plan[5] = g.QT; plan[6] = g.nQG;
     plan[7] = g.KVS * 32;
@@ -1102,6 +1127,8 @@ void launch_merge_np(const MergeParams& mp, unsigned blocks, hipStream_t stream)
         case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
         case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
         case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 9: hipLaunchKernelGGL((merge_kernel<VEC, 9, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 12: hipLaunchKernelGGL((merge_kernel<VEC, 12, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
         default: hipLaunchKernelGGL((merge_kernel<VEC, 0, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
     }
 }
