@@ -62,6 +62,7 @@ def parse_args(argv=None):
                     help="feature store layout of the key/value pairs: the kernels' operand layout, or tensors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (host UNet around the path)")
+    ap.add_argument("--no-block-skip", action="store_true", help="skip the SID_FLAG_BLOCK_SKIP on/off record")
     ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
@@ -244,6 +245,44 @@ def kernel_records(w, compute):
           "achieved": hf_bytes / t_hf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hf_bytes / t_hf / HBM_PEAK,
           "algorithmic_bytes": hf_bytes}
     return roof, hf
+
+
+def block_skip_record(dev, compute):
+    """SID_FLAG_BLOCK_SKIP on and off on the top injected layer, (B,8,4096,40), key/value pairs pre-packed,
+    the bench's disc mask, at TWO logit sizes: the unit-variance synthetic features of the headline
+    workload (no block can be proven dead there: the flag only costs) and features three times larger,
+    where the mask bias pushes the far style block and mostly the content block below f32 resolution.
+    Not part of `value`: the headline runs without the flag."""
+    import torch
+    from style_transfer_amd import ops
+    N, d = 4096, 40
+    gen = torch.Generator(device=dev); gen.manual_seed(4242)
+    yy, xx = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
+    disc = (((yy - 255.5) ** 2 + (xx - 255.5) ** 2) <= (0.3 * 512) ** 2).float().contiguous()
+    mask1 = ops.mask_downsample(disc, 64, 64, 1.0).reshape(1, -1).contiguous()
+    mode = compute if compute != "fp32" else "bf16"          # the flag does not apply to the f32-grade mode
+    rec = {"layer": "injected attention (B,8,4096,40), disc mask r=0.3, pre-packed key/value pairs, %s" % mode, "cases": []}
+    for sigma in (1.0, 3.0):
+        for B in (1, 16):
+            rn = lambda *s: torch.randn(*s, device=dev, generator=gen) * sigma
+            xq, q_cnt = rn(B, N, HEADS * d), rn(B * HEADS, N, d)
+            kv = [ops.pack_kv(rn(B * HEADS, N, d), rn(B * HEADS, N, d), HEADS, mode) for _ in range(3)]
+            mask = mask1.repeat(B, 1).contiguous()
+            out = torch.empty_like(xq)
+            call = lambda fl: ops.injected_attention_packed(xq, q_cnt, kv[0], kv[1], kv[2], mask, GAMMA, TEMP, d ** -0.5,
+                                                            HEADS, out=out, flags=fl)
+            reps = 200 if B == 1 else 20
+            t_off = events_per_call(lambda: call(0), reps)
+            t_on = events_per_call(lambda: call(ops.FLAG_BLOCK_SKIP), reps)
+            call(ops.FLAG_BLOCK_SKIP)
+            counts = ops.skip_counts(xq, HEADS, mode, packed=True)
+            rec["cases"].append({"B": B, "feature_sigma": sigma, "call_ms_flag_off": t_off * 1e3, "call_ms_flag_on": t_on * 1e3,
+                                 "time_ratio": t_on / t_off,
+                                 "query_groups": counts[3], "groups_with_a_dead_style_block": counts[0],
+                                 "content_segments_logits_only": counts[1], "of_those_redone_in_full": counts[2]})
+            del xq, q_cnt, kv, out
+            torch.cuda.empty_cache()
+    return rec
 
 
 def measured_traffic():
@@ -499,10 +538,12 @@ def run_rank(args, world, rank, local):
         if world == 1:
             del lanes[1:]
             torch.cuda.empty_cache()
+            line["block_skip"] = None if args.no_block_skip else block_skip_record(dev, args.compute)
             line["e2e"] = None if args.no_e2e else e2e_record(dev, args.compute, args.store)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         else:
             line["e2e"] = None
+            line["block_skip"] = None
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -52,9 +52,9 @@ extern "C" {
 
 /* flags (bit mask) */
 /* Injected attention only: leave out a key block for a workgroup of queries when its whole softmax mass is
- * provably below half an ulp of the f32 row sums.  The mask bias separates the two style blocks by
- * 2 * |m| * (max q.k - min cc) / ... logits: at feature-sized logits the style block of the far mask side
- * weighs nothing on every row with |mask| > T * scale, and often the content block does not either.
+ * provably below half an ulp of the f32 row sums.  The mask bias (min cc - max q.k) * (-+m) is built from
+ * raw products: at feature-sized logits it sinks the style block of the far mask side below f32
+ * resolution on every row with |mask| > T * scale, and often the content block with it.
  * With the flag the queries of an image are regrouped by mask side (workgroups then sit on one side
  * whatever the shape of the region), every workgroup bounds its rows' logits from sampled key tiles and
  *   - drops the far style block for all its rows when the bounds prove it dead (the two remaining

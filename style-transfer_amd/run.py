@@ -58,6 +58,9 @@ def build_parser():
                         "layers (same speed, finer logits); fp32 = split-bf16, f32-grade")
     p.add_argument('--feature_dtype', default='float32', choices=['float32', 'bfloat16'], help="storage type of the feature store in HBM")
     p.add_argument('--graph_unet', action='store_true', help="replay every UNet evaluation as one HIP graph (not with a residual file)")
+    p.add_argument('--block_skip', action='store_true',
+                   help="injected attention leaves out key blocks whose softmax mass is provably nil (SID_FLAG_BLOCK_SKIP): "
+                        "pays at the logit sizes of real features, costs where no block can be dropped")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
@@ -109,6 +112,12 @@ def stylise(opt, model, sampler, triple, uc, device):
     from .high_frequency import make_content_injection_schedule, patch_decoder_resblocks_h_and_cnt_hf
     cnt_path, char_path, back_path = triple
     model.set_content_name(cnt_path)                                   # run_ori.py:159-161
+    if getattr(opt, "block_skip", False):
+        from . import ops
+        from .attention import CrossAttention
+        for m in model.modules():
+            if isinstance(m, CrossAttention):
+                m.kernel_flags |= ops.FLAG_BLOCK_SKIP
     dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
     store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype)
     mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")

@@ -173,3 +173,27 @@ def test_every_head_dim_up_to_160_has_a_kernel_and_huge_key_counts_are_refused()
     assert b"stages" in L.sid_last_error()
     assert L.sid_kv_image_bytes(1, 8, 4096, 40, 0) == 8 * 4096 * (48 + 64) * 2
     assert L.sid_injected_attn_packed_workspace_bytes(1, 8, 4096, 40, 0) < L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, 0)
+
+
+def test_block_skip_planning_queries():
+    """SID_FLAG_BLOCK_SKIP: the plan accounts for the launch's padding groups, the counters have a place in
+    the workspace exactly where the flag applies, and the workspace covers either decomposition."""
+    import ctypes
+    from style_transfer_amd import lib
+    L = lib.load()
+    plan = (ctypes.c_int * 40)()
+    assert L.sid_attn_plan(3, 1, 8, 4096, 4096, 40, lib.COMPUTE_BF16, 0, plan) == 0
+    w_off = plan[0]
+    assert L.sid_attn_plan(3, 1, 8, 4096, 4096, 40, lib.COMPUTE_BF16, 1, plan) == 0
+    w_on = plan[0]
+    # 8 heads x (8 + 2) query groups x W workgroups of one CU each must fit the 256 CUs in one round
+    assert w_off == 4 and w_on == 3 and 8 * 10 * w_on <= 256
+    assert list(plan[8:8 + w_on + 1]) == [0, 64, 128, 192]
+    ws = L.sid_injected_attn_workspace_bytes(1, 8, 4096, 40, lib.COMPUTE_BF16)
+    for packed in (0, 1):
+        off = L.sid_injected_attn_skip_counts_offset(1, 8, 4096, 40, lib.COMPUTE_BF16, 1, packed)
+        assert 0 < off and off % 256 == 0 and off + 16 <= ws
+    assert L.sid_injected_attn_skip_counts_offset(1, 8, 4096, 40, lib.COMPUTE_BF16, 0, 0) == -1        # flag off
+    assert L.sid_injected_attn_skip_counts_offset(1, 8, 4096, 40, lib.COMPUTE_F32X3, 1, 0) == -1      # f32-grade mode
+    assert L.sid_injected_attn_skip_counts_offset(1, 8, 1024, 80, lib.COMPUTE_BF16, 1, 0) == -1        # short key blocks
+    assert ws <= lib.STATIC_SCRATCH_BYTES
