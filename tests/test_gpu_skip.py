@@ -175,3 +175,63 @@ def test_packed_entry_point_takes_the_flag():
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     unpacked = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
     assert torch.equal(unpacked, skipped)
+
+
+@pytest.mark.parametrize("N,d", [(2048, 160), (2048, 96), (2048, 128), (2048, 24), (2080, 64)])
+def test_other_kernel_instances(N, d):
+    """Head dims whose instances stage one key tile per stage or hold a shorter key-only ring."""
+    t = inputs(7400 + d, 1, N, d, 3.0, "disc")
+    plain = run(t, d, "bf16", 0)
+    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    print("N=%d d=%d: counts %s" % (N, d, (dead, lo, redone, groups)))
+    assert dead == groups and lo > 0
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    rows = (synth.hash_u64(7401, 8) % np.uint64(N)).astype(np.int64)
+    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+
+
+def test_images_with_different_masks_and_bf16_storage():
+    """Every image of a batch is regrouped by its own mask; bf16 tensors in and out."""
+    N, d = 4096, 40
+    t = inputs(7500, 3, N, d, 3.0, "disc")
+    t["mask"][1] = 1.0                        # one side only: a single run of groups, no padding between sides
+    t["mask"][2] = -t["mask"][2]
+    plain = run(t, d, "bf16", 0)
+    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    assert groups == H * (9 + 8 + 9) and dead == groups
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    tb = {k: (v.to(torch.bfloat16) if k != "mask" else v) for k, v in t.items()}
+    plain_b = run(tb, d, "bf16", 0)
+    skipped_b = run(tb, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    assert skipped_b.dtype == torch.bfloat16
+    assert (plain_b.float() - skipped_b.float()).abs().max().item() <= 2 * SAME_BAND * plain.abs().max().item()
+
+
+def test_static_scratch_and_graph_replay_with_the_flag():
+    N, d = 4096, 40
+    t = inputs(7600, 1, N, d, 3.0, "disc")
+    eager = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP).clone()
+    out = torch.empty_like(eager)
+    static = ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"], t["mask"],
+                                    0.5, 1.5, d ** -0.5, H, compute="bf16", out=out, flags=ops.FLAG_BLOCK_SKIP,
+                                    static_scratch=True)
+    assert torch.equal(static, eager)
+    st = torch.cuda.Stream()
+    gout = torch.empty_like(eager)
+    call = lambda: ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"],
+                                          t["mask"], 0.5, 1.5, d ** -0.5, H, compute="bf16", out=gout,
+                                          flags=ops.FLAG_BLOCK_SKIP)
+    with torch.cuda.stream(st):
+        call()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+        call()
+    gout.zero_()
+    t["mask"].neg_()                          # the regrouping is part of the graph: a new mask is picked up
+    graph.replay()
+    torch.cuda.synchronize()
+    flipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    assert torch.equal(gout, flipped)
