@@ -235,3 +235,35 @@ def test_static_scratch_and_graph_replay_with_the_flag():
     torch.cuda.synchronize()
     flipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
     assert torch.equal(gout, flipped)
+
+
+def test_random_shapes_and_masks():
+    """Random shapes, scales and blob masks: the flagged call stays within the decomposition band of the
+    unflagged one, and the counters stay consistent."""
+    rng = np.random.default_rng(7700)
+    for case in range(16):
+        N = int(rng.integers(2048, 5200))
+        d = int(rng.choice([24, 40, 48, 64, 80, 96, 128, 160]))
+        B = int(rng.integers(1, 3))
+        sigma = float(rng.choice([1.5, 2.0, 3.0]))
+        t = inputs(7701 + case, B, N, d, sigma, "random")
+        # blobs: a few runs of tokens on the other side, some rows soft, some exactly zero
+        m = torch.ones(B, N, device="cuda:0")
+        for b in range(B):
+            for _ in range(int(rng.integers(0, 6))):
+                a = int(rng.integers(0, N)); w = int(rng.integers(1, N // 2))
+                m[b, a:a + w] = -1
+            soft = torch.from_numpy(rng.random(N) < 0.02).to("cuda:0")
+            m[b, soft] *= 0.1
+            m[b, int(rng.integers(0, N))] = 0.0
+        t["mask"] = m.contiguous()
+        compute = "f16" if (33 <= d <= 48 or 65 <= d <= 80) and case % 2 else "bf16"
+        plain = run(t, d, compute, 0)
+        skipped = run(t, d, compute, ops.FLAG_BLOCK_SKIP)
+        dead, lo, redone, groups = ops.skip_counts(t["xq"], H, compute)
+        diff = (plain - skipped).abs().max().item() / plain.abs().max().item()
+        print("case %d: B=%d N=%d d=%d sigma=%.1f %s: counts %s diff %.1e" % (case, B, N, d, sigma, compute,
+                                                                             (dead, lo, redone, groups), diff))
+        assert torch.isfinite(skipped).all()
+        assert dead <= groups and redone <= lo and groups > 0
+        assert diff <= SAME_BAND
