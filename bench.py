@@ -293,7 +293,12 @@ def measured_traffic():
     if not files:
         return {"traffic": None}
     with open(files[-1]) as f:
-        return {"traffic": json.load(f).get("traffic_bytes"), "traffic_source": "profiles/" + os.path.basename(files[-1])}
+        js = json.load(f)
+    # mfma_busy: matrix-pipe busy cycles over the dispatch's SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES against
+    # GRBM_GUI_ACTIVE), the hardware's own utilisation figure beside the algorithmic `frac` (which counts
+    # neither the padding of head_dim 40 to the MFMA shapes nor the clock the chip sustains)
+    return {"traffic": js.get("traffic_bytes"), "mfma_busy": js.get("mfma_busy"), "valu_issue_busy": js.get("valu_issue_busy"),
+            "traffic_source": "profiles/" + os.path.basename(files[-1])}
 
 
 def e2e_record(dev, compute, store):

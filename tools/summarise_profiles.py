@@ -52,6 +52,10 @@ if flash and "FETCH_SIZE" in flash:
           "fetch_bytes": flash["FETCH_SIZE"] * 1024 * 2, "write_bytes": flash.get("WRITE_SIZE", 0.0) * 1024,
           "correction": "FETCH_SIZE x2 (gfx950 counts 128 B read requests as 64 B), WRITE_SIZE x1; KiB -> bytes"}
     js["traffic_bytes"] = js["fetch_bytes"] + js["write_bytes"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in flash and "GRBM_GUI_ACTIVE" in flash:
+        # hardware-counter utilisation of the matrix pipe: busy cycles over the SIMD-cycles of the dispatch
+        js["mfma_busy"] = flash["SQ_VALU_MFMA_BUSY_CYCLES"] / (flash["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        js["valu_issue_busy"] = 4 * flash.get("SQ_ACTIVE_INST_VALU", 0) / (flash["GRBM_GUI_ACTIVE"] / 8 * 1024)
     json.dump(js, open(os.path.join(dst, tag + "_flash_traffic.json"), "w"), indent=1)
     print(js)
 print("\n".join(lines[:60]))
