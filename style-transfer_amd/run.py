@@ -171,13 +171,21 @@ def main(argv=None):
         raise SystemExit("style_transfer_amd.run needs a GPU: the path has no CPU fallback")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a box with one GPU: SID_DIST_BACKEND=gloo gathers through the host, SID_ONE_DEVICE=1 puts
+    # every rank on GPU 0.  Production is one rank per GPU with nccl (= RCCL over xGMI).
+    backend = os.environ.get("SID_DIST_BACKEND", "nccl")
+    if os.environ.get("SID_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     torch.manual_seed(opt.seed)
     set_default_compute(opt.compute)
     os.makedirs(opt.output_path, exist_ok=True)
@@ -199,6 +207,8 @@ def main(argv=None):
     shape = (opt.C, opt.H // opt.f, opt.W // opt.f)
     local_stack = torch.stack(latents) if latents else torch.zeros((0,) + shape, device=device)
     local_stack, _ = sharding.pad_to_common(local_stack, len(triples), world)
+    if dist is not None and backend != "nccl":
+        local_stack = local_stack.cpu()
     gathered = sharding.gather_latents(local_stack, dist, dst=0)
     if rank == 0:
         allz = sharding.reassemble(gathered, len(triples))
