@@ -267,3 +267,18 @@ def test_random_shapes_and_masks():
         assert torch.isfinite(skipped).all()
         assert dead <= groups and redone <= lo and groups > 0
         assert diff <= SAME_BAND
+
+
+def test_with_the_throughput_decomposition():
+    """SID_FLAG_THROUGHPUT | SID_FLAG_BLOCK_SKIP: three runs per query group; where a style block is dead they
+    share the two remaining blocks."""
+    N, d = 4096, 40
+    t = inputs(7800, 2, N, d, 3.0, "disc")
+    both = ops.FLAG_BLOCK_SKIP | ops.FLAG_THROUGHPUT
+    plain = run(t, d, "bf16", ops.FLAG_THROUGHPUT)
+    skipped = run(t, d, "bf16", both)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16", flags=both)
+    assert dead == groups and groups == 2 * H * 9 and lo > 0 and redone <= lo
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    rows = (synth.hash_u64(7801, 8) % np.uint64(N)).astype(np.int64)
+    assert rel_err(skipped[1].cpu().numpy()[rows], oracle_rows(t, 1, rows, d)) < 3.5e-2
