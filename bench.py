@@ -110,14 +110,15 @@ def main(argv=None):
 # ----------------------------------------------------------------------------------------------
 # everything below runs inside one rank
 # ----------------------------------------------------------------------------------------------
-def make_image_workload(dev, gen, dtype, store, compute):
+def make_image_workload(dev, gen, dtype, store, compute, sigma=1.0):
     """All tensors the hot path of one image reads, resident on `dev`: per evaluation its own query
-    projection, feature tensors (or packed key/value pairs), plain-attention inputs and content maps."""
+    projection, feature tensors (or packed key/value pairs), plain-attention inputs and content maps.
+    `sigma` scales the attention tensors (1: the headline's unit-variance features)."""
     import torch
     from style_transfer_amd import ops
 
     def rn(*shape):
-        return torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen).to(dtype)
+        return (torch.randn(*shape, device=dev, dtype=torch.float32, generator=gen) * sigma).to(dtype)
 
     w = {"inj": [], "plain": [], "hf": [], "store": store}
     w["z"] = [rn(1, 4, 64, 64).float() for _ in range(3)]          # inverted latents: content / char / back
@@ -282,6 +283,39 @@ def block_skip_record(dev, compute):
                                  "content_segments_logits_only": counts[1], "of_those_redone_in_full": counts[2]})
             del xq, q_cnt, kv, out
             torch.cuda.empty_cache()
+    # the whole hot path of an image, three images in flight, at the feature-sized logits: the headline's
+    # loop with and without the flag (only the three N = 4096 injected layers are long enough to take it)
+    n_lanes, images = 3, 12
+    lanes = []
+    for li in range(n_lanes):
+        gen.manual_seed(4300 + li)
+        w = make_image_workload(dev, gen, torch.float32, "packed", mode, sigma=3.0)
+        st = torch.cuda.Stream(device=dev)
+        graphs = {}
+        for name, fl in (("off", ops.FLAG_THROUGHPUT), ("on", ops.FLAG_THROUGHPUT | ops.FLAG_BLOCK_SKIP)):
+            with torch.cuda.stream(st):
+                run_image(w, mode, fl)
+            torch.cuda.synchronize()
+            graphs[name] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[name], stream=st, capture_error_mode="thread_local"):
+                run_image(w, mode, fl)
+        lanes.append((st, graphs, w))
+    rates = {}
+    for name in ("off", "on"):
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(images):
+                st, graphs, _ = lanes[i % n_lanes]
+                with torch.cuda.stream(st):
+                    graphs[name].replay()
+            torch.cuda.synchronize()
+            if timed:
+                rates[name] = images / (time.perf_counter() - t0)
+    rec["image"] = {"what": "hot path of one image as in `value`, 3 images in flight, attention tensors x3 (feature-sized logits)",
+                    "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"], "ratio": rates["on"] / rates["off"]}
+    del lanes
+    torch.cuda.empty_cache()
     return rec
 
 
