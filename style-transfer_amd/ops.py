@@ -115,14 +115,17 @@ FLAG_BLOCK_SKIP = 1      # SID_FLAG_BLOCK_SKIP: drop key blocks whose softmax ma
 
 def skip_counts(x_q, heads, compute="bf16", flags=FLAG_BLOCK_SKIP, packed=False):
     """The block-skipping counters of the last injected-attention call made on the current stream with this
-    shape: (segments dropped, content segments reduced to logits, of those redone in full, segments seen),
-    or None where the flag has no effect.  Synchronises."""
+    shape, mode, flags and entry point: (query groups with a dead style block, content segments reduced to
+    their logits, of those redone in full, query groups), or None where the flag has no effect (then the
+    call ran as if it were not set).  Synchronises."""
     L = _lib.load()
     B, N, C = x_q.shape
     off = L.sid_injected_attn_skip_counts_offset(B, heads, N, C // heads, _compute_code(compute), int(flags), int(packed))
     if off < 0:
         return None
-    ws = _workspaces[(x_q.device.index, _stream(x_q.device))]
+    ws = _workspaces.get((x_q.device.index, _stream(x_q.device)))
+    if ws is None or off + 16 > ws.numel():
+        raise RuntimeError("no injected-attention call with this shape has run on the current stream")
     return tuple(int(v) for v in ws[off:off + 16].view(torch.int32).cpu())
 
 
