@@ -282,3 +282,37 @@ def test_with_the_throughput_decomposition():
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     rows = (synth.hash_u64(7801, 8) % np.uint64(N)).astype(np.int64)
     assert rel_err(skipped[1].cpu().numpy()[rows], oracle_rows(t, 1, rows, d)) < 3.5e-2
+
+
+def test_token_regrouping_matches_a_stable_partition():
+    """White box: the token order the pack launch leaves in the workspace (4 counters, one group count per
+    head slot, then positions x images) against numpy: sides [m > ts | between | m < -ts] in token order,
+    every side padded with -1 to a whole workgroup of 512 queries."""
+    from style_transfer_amd import lib
+    N, d, B = 4096, 40, 2
+    t = inputs(7900, B, N, d, 3.0, "random")
+    rng = np.random.default_rng(7901)
+    m = np.where(rng.random((B, N)) < 0.3, 1.0, -1.0).astype(np.float32)
+    m[0, rng.random(N) < 0.1] = 0.1                       # below T * scale = 0.237: the middle side
+    m[1, :] = 1.0                                           # a single side
+    t["mask"] = torch.from_numpy(m).to("cuda:0")
+    run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    torch.cuda.synchronize()
+    L = lib.load()
+    off = L.sid_injected_attn_skip_counts_offset(B, H, N, d, lib.COMPUTE_BF16, 1, 0)
+    ws = ops._workspaces[(0, torch.cuda.current_stream().cuda_stream)]
+    GR, groups_max = 512, N // 512 + 2
+    NP = groups_max * GR
+    goff = off + 256
+    roff = goff + ((B * H * 4 + 255) // 256) * 256
+    groups = ws[goff:goff + 4 * B].view(torch.int32).cpu().numpy()
+    rowmap = ws[roff:roff + 4 * B * NP].view(torch.int32).cpu().numpy().reshape(B, NP)
+    ts = 1.5 * d ** -0.5
+    for b in range(B):
+        want = []
+        for side in (m[b] > ts, np.abs(m[b]) <= ts, m[b] < -ts):
+            tok = np.nonzero(side)[0]
+            want += list(tok) + [-1] * (-len(tok) % GR)
+        assert groups[b] == len(want) // GR
+        want += [-1] * (NP - len(want))
+        assert np.array_equal(rowmap[b], np.array(want, dtype=np.int32)), b
