@@ -67,6 +67,10 @@ class CrossAttention(nn.Module):
         self.layer_id = None
         self.compute = None          # None: follow set_default_compute()
         self.kernel_flags = 0        # e.g. ops.FLAG_THROUGHPUT when several images share the GPU
+        # ops.FLAG_BLOCK_SKIP pays only where the logits are large enough for blocks to die.  "auto": after the
+        # layer's next flagged call the counters are read once (one synchronisation) and the flag is dropped
+        # for this layer unless at least half of the query groups lost a style block; "fixed": leave it alone.
+        self.skip_policy = "fixed"
         self.mask_cache = default_cache
         self._q = None
         self._q_lazy = None
@@ -133,6 +137,7 @@ class CrossAttention(nn.Module):
                 out = ops.injected_attention_packed(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, cnt_k_injected, m,
                                                     gamma, T, self.scale, self.heads, q_self_coef=0.5,
                                                     flags=self.kernel_flags)
+                self._review_block_skip(xq, k_injected.compute, True)
                 return self.to_out(out)
             feats = [q_injected, k_injected, v_injected, sty2_k_injected, sty2_v_injected, cnt_k_injected,
                      cnt_v_injected]
@@ -178,8 +183,23 @@ class CrossAttention(nn.Module):
         compute = resolve_compute(compute, xq.shape[1], d, min(abs(T), 1.0) * self.scale if T else self.scale)
         if compute == "f16":
             compute = resolve_compute(compute, xq.shape[1], d, max(abs(T), 1.0) * self.scale)
-        return ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute,
-                                      flags=self.kernel_flags)
+        out = ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute,
+                                     flags=self.kernel_flags)
+        self._review_block_skip(xq, compute, False)
+        return out
+
+    def _review_block_skip(self, xq, compute, packed):
+        """skip_policy "auto": keep ops.FLAG_BLOCK_SKIP on this layer only if the call just made dropped a style
+        block for at least half of its query groups (where nothing can be dropped the flag costs about a
+        fifth of the call).  Decided once per arming (run.py arms it per image); never during graph capture."""
+        if self.skip_policy != "auto" or not (self.kernel_flags & ops.FLAG_BLOCK_SKIP):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        counts = ops.skip_counts(xq, self.heads, compute, self.kernel_flags, packed)
+        if counts is None or 2 * counts[0] < counts[3]:
+            self.kernel_flags &= ~ops.FLAG_BLOCK_SKIP
+        self.skip_policy = "fixed"
 
     def _plain(self, q, k, v, logit_scale, q_layout, kv_layout, compute):
         n_keys = k.shape[1]

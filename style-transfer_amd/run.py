@@ -59,8 +59,8 @@ def build_parser():
     p.add_argument('--feature_dtype', default='float32', choices=['float32', 'bfloat16'], help="storage type of the feature store in HBM")
     p.add_argument('--graph_unet', action='store_true', help="replay every UNet evaluation as one HIP graph (not with a residual file)")
     p.add_argument('--block_skip', action='store_true',
-                   help="injected attention leaves out key blocks whose softmax mass is provably nil (SID_FLAG_BLOCK_SKIP): "
-                        "pays at the logit sizes of real features, costs where no block can be dropped")
+                   help="injected attention leaves out key blocks whose softmax mass is provably nil (SID_FLAG_BLOCK_SKIP); "
+                        "every layer keeps the flag for an image only if its first call dropped something")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
@@ -117,7 +117,8 @@ def stylise(opt, model, sampler, triple, uc, device):
         from .attention import CrossAttention
         for m in model.modules():
             if isinstance(m, CrossAttention):
-                m.kernel_flags |= ops.FLAG_BLOCK_SKIP
+                m.kernel_flags |= ops.FLAG_BLOCK_SKIP      # kept per layer only where blocks actually die
+                m.skip_policy = "auto"
     dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
     store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype)
     mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")

@@ -316,3 +316,27 @@ def test_token_regrouping_matches_a_stable_partition():
         assert groups[b] == len(want) // GR
         want += [-1] * (NP - len(want))
         assert np.array_equal(rowmap[b], np.array(want, dtype=np.int32)), b
+
+
+@pytest.mark.parametrize("sigma,kept", [(3.0, True), (1.0, False)])
+def test_auto_policy_keeps_the_flag_only_where_blocks_die(sigma, kept, tmp_path):
+    """CrossAttention with skip_policy "auto": the first flagged call decides for the layer."""
+    from style_transfer_amd.attention import CrossAttention
+    N, d = 4096, 40
+    t = inputs(7950, 1, N, d, sigma, "disc")
+    np.save(str(tmp_path / "img_mask.npy"), (t["mask"][0].reshape(64, 64) > 0).float().cpu().numpy())
+    attn = CrossAttention(query_dim=H * d, heads=H, dim_head=d).to("cuda:0")
+    with torch.no_grad():
+        attn.to_q.weight.copy_(torch.eye(H * d)); attn.to_out[0].weight.copy_(torch.eye(H * d)); attn.to_out[0].bias.zero_()
+    attn.cnt_name = str(tmp_path / "img.jpg")
+    attn.kernel_flags |= ops.FLAG_BLOCK_SKIP
+    attn.skip_policy = "auto"
+    kw = dict(q_injected=t["q_cnt"], k_injected=t["k1"], v_injected=t["v1"], sty2_k_injected=t["k2"], sty2_v_injected=t["v2"],
+              cnt_k_injected=t["k_cnt"], cnt_v_injected=t["v_cnt"], injection_config={"T": 1.5, "gamma": 0.5})
+    with torch.no_grad():
+        first = attn(t["xq"], **kw)
+        assert attn.skip_policy == "fixed" and bool(attn.kernel_flags & ops.FLAG_BLOCK_SKIP) == kept
+        second = attn(t["xq"], **kw)
+    ref = run(t, d, "bf16", 0)
+    for out in (first, second):
+        assert (out - ref).abs().max().item() <= SAME_BAND * ref.abs().max().item()
