@@ -250,9 +250,10 @@ def kernel_records(w, compute):
 
 def block_skip_record(dev, compute):
     """SID_FLAG_BLOCK_SKIP on and off on the top injected layer, (B,8,4096,40), key/value pairs pre-packed,
-    the bench's disc mask, at TWO logit sizes: the unit-variance synthetic features of the headline
-    workload (no block can be proven dead there: the flag only costs) and features three times larger,
-    where the mask bias pushes the far style block and mostly the content block below f32 resolution.
+    the bench's disc mask, at three logit sizes: the unit-variance synthetic features of the headline
+    workload (no block can be proven dead there: the flag only costs), features twice as large (the far
+    style block is dead everywhere, the content block is not) and three times as large (the mask bias
+    pushes the far style block and mostly the content block below f32 resolution).
     Not part of `value`: the headline runs without the flag."""
     import torch
     from style_transfer_amd import ops
@@ -263,7 +264,7 @@ def block_skip_record(dev, compute):
     mask1 = ops.mask_downsample(disc, 64, 64, 1.0).reshape(1, -1).contiguous()
     mode = compute if compute != "fp32" else "bf16"          # the flag does not apply to the f32-grade mode
     rec = {"layer": "injected attention (B,8,4096,40), disc mask r=0.3, pre-packed key/value pairs, %s" % mode, "cases": []}
-    for sigma in (1.0, 3.0):
+    for sigma in (1.0, 2.0, 3.0):
         for B in (1, 16):
             rn = lambda *s: torch.randn(*s, device=dev, generator=gen) * sigma
             xq, q_cnt = rn(B, N, HEADS * d), rn(B * HEADS, N, d)
