@@ -102,11 +102,14 @@ __device__ __forceinline__ float load_elem(const void* p, long long idx) {
     return ((const float*)p)[idx];
 }
 
-// Regrouping of one image's tokens by mask side: [m > ts | in between | m < -ts], stable, every side
-// starting on a multiple of GR positions (the queries of one workgroup) with -1 in the gaps.  A region
-// boundary cuts through the rows of the feature map, so in token order most workgroups straddle it;
-// regrouped, none does, and a workgroup can drop the style block of the far side for all its rows.  Only
-// the order in which workgroups pick up queries changes: the images stay in token order.
+// Regrouping of one image's tokens by mask side: [m > thr | the rest | padding | m < -thr | padding], stable,
+// the second side starting on a multiple of GR positions (the queries of one workgroup), -1 in the gaps.
+// A region boundary cuts through the rows of the feature map, so in token order most workgroups straddle
+// it; regrouped, none does, and a workgroup can drop the style block of the far side for all its rows.
+// The rows in between (|m| <= thr: the mask's blurred boundary, a few dozen tokens of a real mask, for
+// which no block can be dropped) ride behind the first side: they cost that side's last workgroup its
+// dropped block instead of a workgroup of their own.  Only the order in which workgroups pick up queries
+// changes: the images stay in token order.
 __device__ void rowmap_block(const PackParams& P, int b) {
     constexpr int kThreads = 256, kWaves = kThreads / 64;
     __shared__ int wave_sum[3][kWaves];
@@ -150,7 +153,7 @@ __device__ void rowmap_block(const PackParams& P, int b) {
         for (int k = 0; k < 3; ++k) wave_sum[k][wv] = cnt[k];
     }
     __syncthreads();
-    int start = 0, first[3], total[3], base[3];
+    int first[3], total[3], base[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int lower = 0;
@@ -161,10 +164,14 @@ __device__ void rowmap_block(const PackParams& P, int b) {
             lower += w < wv ? n : 0;
             total[k] += n;
         }
-        first[k] = start;
-        base[k] = start + lower;
-        start += (total[k] + GR - 1) / GR * GR;
+        base[k] = lower;
     }
+    first[0] = 0;
+    first[1] = total[0];
+    first[2] = (total[0] + total[1] + GR - 1) / GR * GR;
+    const int start = first[2] + (total[2] + GR - 1) / GR * GR;      // positions in use
+#pragma unroll
+    for (int k = 0; k < 3; ++k) base[k] += first[k];
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int s0 = 0; s0 < steps; s0 += kBatch) {
         int c[kBatch];
@@ -181,9 +188,7 @@ __device__ void rowmap_block(const PackParams& P, int b) {
         }
     }
     for (int p = tid; p < P.rm_NP; p += kThreads) {
-        bool gap = p >= start;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gap |= p >= first[k] + total[k] && p < first[k] + (total[k] + GR - 1) / GR * GR;
+        const bool gap = (p >= total[0] + total[1] && p < first[2]) || p >= first[2] + total[2];
         if (gap) out[p] = -1;
     }
     if (tid == 0) P.rm_groups[b] = start / GR;
@@ -726,7 +731,8 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
         pp.job[1].post = c2c;
         if (skip) {
             pp.rm_mask = mask_signed; pp.rm_out = w.rowmap; pp.rm_groups = w.rowmap_groups; pp.rm_counters = w.skip_count;
-            pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32; pp.rm_ts = T * scale;
+            pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32;
+            pp.rm_ts = std::max(T * scale, 0.5f);    // |m| <= 1/2: the blurred boundary of a +-1 mask (its values are +-1, +-1/2, 0)
         }
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};

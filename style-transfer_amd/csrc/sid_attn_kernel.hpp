@@ -65,9 +65,9 @@ struct FlashParams {
     unsigned char first_run[kBlocks];     // the run that holds a block's first stage
     unsigned char nseg[kBlocks];          // runs that overlap a block = partial slots it uses (<= KS)
     // SID_FLAG_BLOCK_SKIP (rowmap null: off; served by the SKIP kernel instances).  The queries of an image
-    // are regrouped by mask side: position i of image b holds token rowmap[b * NP + i] (-1: padding; every
-    // side starts on a workgroup boundary, so no workgroup straddles two sides), rowmap_groups[b] query
-    // groups are in use (nQG counts the launch's groups: up to two more than the tokens need).  Every
+    // are regrouped by mask side: position i of image b holds token rowmap[b * NP + i] (-1: padding; the
+    // second side starts on a workgroup boundary, so no workgroup straddles the two sides), rowmap_groups[b]
+    // query groups are in use (nQG counts the launch's groups: one more than the tokens need).  Every
     // workgroup bounds the logits of its rows from nsamp sampled key tiles per block (tiles j * samp_stride)
     // and drops what the bounds prove dead (margin dead_gap, see kDeadGapBase; ts = T * scale).  A group
     // with a dead style block runs the two remaining blocks as ONE sequence of 2 * SPB stages cut by
@@ -206,7 +206,7 @@ enum { kOnline = 0, kFixed = 1, kShifted = 2 };
 // lies more than kDeadGapBase + log2(keys of the block) log2 units under a logit the row is known to hold.
 constexpr float kDeadGapBase = 26.f;
 constexpr int kProbeTiles = 4;        // key tiles (of 32 keys) sampled per block for the bounds
-constexpr int kSkipPadGroups = 2;     // query groups a launch adds for the padding between mask sides
+constexpr int kSkipPadGroups = 1;     // query groups a launch adds for the padding between the two mask sides
 
 __device__ __forceinline__ float max16(const f32x16& S) {
     float t = fmaxf(fmaxf(S[0], S[1]), S[2]);
