@@ -92,7 +92,7 @@ struct PackParams {
     int* rm_out;            // [B][rm_NP]
     int* rm_groups;         // [B]
     unsigned* rm_counters;  // the call's four skip counters, zeroed here
-    int rm_blocks, rm_N, rm_NP, rm_GR;
+    int rm_blocks, rm_N, rm_NP, rm_GR, rm_own_middle;
     float rm_ts;
 };
 
@@ -102,14 +102,19 @@ __device__ __forceinline__ float load_elem(const void* p, long long idx) {
     return ((const float*)p)[idx];
 }
 
-// Regrouping of one image's tokens by mask side: [m > thr | the rest | padding | m < -thr | padding], stable,
-// the second side starting on a multiple of GR positions (the queries of one workgroup), -1 in the gaps.
+// Regrouping of one image's tokens by mask side: [m > thr | the rest | m < -thr], stable, -1 in the gaps.
 // A region boundary cuts through the rows of the feature map, so in token order most workgroups straddle
 // it; regrouped, none does, and a workgroup can drop the style block of the far side for all its rows.
 // The rows in between (|m| <= thr: the mask's blurred boundary, a few dozen tokens of a real mask, for
-// which no block can be dropped) ride behind the first side: they cost that side's last workgroup its
-// dropped block instead of a workgroup of their own.  Only the order in which workgroups pick up queries
-// changes: the images stay in token order.
+// which no block can be dropped) go one of two ways (rm_own_middle):
+//   1  every side starts on a multiple of GR positions (the queries of one workgroup): the rows in between
+//      get a workgroup of their own, most of whose waves hold padding alone and compute nothing -- a cheap
+//      workgroup, and no other one loses its dropped block.  For launches of one round of workgroups, where
+//      the slowest workgroup sets the time.
+//   0  they ride behind the first side (only the last side starts on a workgroup boundary): they cost that
+//      side's last workgroup its dropped block instead of a workgroup of their own.  Least total work: for
+//      launches that keep the GPU busy for several rounds.
+// Only the order in which workgroups pick up queries changes: the images stay in token order.
 __device__ void rowmap_block(const PackParams& P, int b) {
     constexpr int kThreads = 256, kWaves = kThreads / 64;
     __shared__ int wave_sum[3][kWaves];
@@ -166,10 +171,11 @@ __device__ void rowmap_block(const PackParams& P, int b) {
         }
         base[k] = lower;
     }
+    auto up = [&](int n) { return (n + GR - 1) / GR * GR; };
     first[0] = 0;
-    first[1] = total[0];
-    first[2] = (total[0] + total[1] + GR - 1) / GR * GR;
-    const int start = first[2] + (total[2] + GR - 1) / GR * GR;      // positions in use
+    first[1] = P.rm_own_middle ? up(total[0]) : total[0];
+    first[2] = up(first[1] + total[1]);
+    const int start = first[2] + up(total[2]);      // positions in use
 #pragma unroll
     for (int k = 0; k < 3; ++k) base[k] += first[k];
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -188,7 +194,7 @@ __device__ void rowmap_block(const PackParams& P, int b) {
         }
     }
     for (int p = tid; p < P.rm_NP; p += kThreads) {
-        const bool gap = (p >= total[0] + total[1] && p < first[2]) || p >= first[2] + total[2];
+        const bool gap = (p >= total[0] && p < first[1]) || (p >= first[1] + total[1] && p < first[2]) || p >= first[2] + total[2];
         if (gap) out[p] = -1;
     }
     if (tid == 0) P.rm_groups[b] = start / GR;
@@ -733,6 +739,9 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
             pp.rm_mask = mask_signed; pp.rm_out = w.rowmap; pp.rm_groups = w.rowmap_groups; pp.rm_counters = w.skip_count;
             pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32;
             pp.rm_ts = std::max(T * scale, 0.5f);    // |m| <= 1/2: the blurred boundary of a +-1 mask (its values are +-1, +-1/2, 0)
+            // one round of workgroups (one per CU at 8 waves, two at 4): the slowest workgroup sets the time
+            const long long wgs = (long long)B * H * (g.nQG + kSkipPadGroups) * g.W;
+            pp.rm_own_middle = wgs <= 256LL * (g.NW == 8 ? 1 : 2);
         }
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};

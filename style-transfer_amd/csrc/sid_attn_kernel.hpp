@@ -65,9 +65,10 @@ struct FlashParams {
     unsigned char first_run[kBlocks];     // the run that holds a block's first stage
     unsigned char nseg[kBlocks];          // runs that overlap a block = partial slots it uses (<= KS)
     // SID_FLAG_BLOCK_SKIP (rowmap null: off; served by the SKIP kernel instances).  The queries of an image
-    // are regrouped by mask side: position i of image b holds token rowmap[b * NP + i] (-1: padding; the
-    // second side starts on a workgroup boundary, so no workgroup straddles the two sides), rowmap_groups[b]
-    // query groups are in use (nQG counts the launch's groups: one more than the tokens need).  Every
+    // are regrouped by mask side: position i of image b holds token rowmap[b * NP + i] (-1: padding; sides
+    // start on workgroup boundaries, so no workgroup straddles two of them), rowmap_groups[b] query groups
+    // are in use (nQG counts the launch's groups: up to two more than the tokens need).  A wave whose rows
+    // are all padding takes part in the stage copies and barriers of its workgroup and computes nothing.  Every
     // workgroup bounds the logits of its rows from nsamp sampled key tiles per block (tiles j * samp_stride)
     // and drops what the bounds prove dead (margin dead_gap, see kDeadGapBase; ts = T * scale).  A group
     // with a dead style block runs the two remaining blocks as ONE sequence of 2 * SPB stages cut by
@@ -206,7 +207,7 @@ enum { kOnline = 0, kFixed = 1, kShifted = 2 };
 // lies more than kDeadGapBase + log2(keys of the block) log2 units under a logit the row is known to hold.
 constexpr float kDeadGapBase = 26.f;
 constexpr int kProbeTiles = 4;        // key tiles (of 32 keys) sampled per block for the bounds
-constexpr int kSkipPadGroups = 1;     // query groups a launch adds for the padding between the two mask sides
+constexpr int kSkipPadGroups = 2;     // query groups a launch adds for the padding between the mask sides
 
 __device__ __forceinline__ float max16(const f32x16& S) {
     float t = fmaxf(fmaxf(S[0], S[1]), S[2]);
@@ -622,6 +623,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
 #pragma unroll
         for (int t = 0; t < QT; ++t) tok[t] = P.rowmap[(size_t)b_ * P.NP + (qt0 + t) * 32 + (lane & 31)];
     }
+    // a wave of padding alone (the tail of a mask side): no arithmetic, only its share of copies and barriers
+    bool wave_live = true;
+    if constexpr (SKIP) {
+        bool any_row = false;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) any_row |= tok[t] >= 0;
+        wave_live = __builtin_amdgcn_readfirstlane((int)(__ballot(any_row) != 0ull)) != 0;
+    }
     // token of this lane's row of query tile t, -1 where there is nothing to store
     auto row_token = [&](int t) {
         if constexpr (SKIP) {
@@ -773,8 +782,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 issue_stage(st0 + it + 1, (it + 1) % NB);
                 nissued = it + 2;
             }
-            process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE, QK16>(lds + (it % NB) * SU, lane, hh,
-                                                                   (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
+            if (wave_live)
+                process_stage<DKS, DVB, KVS, X3, QT, TAIL, TMIN, MODE, QK16>(lds + (it % NB) * SU, lane, hh,
+                                                                       (st0 + it) * KVS * 32, P.Nk, qf, O, rs);
             wait_direct_loads();
             __syncthreads();          // stage it+1 has landed in every wave's view; stage it is free
         }
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 if (nissued <= it0 + k && it0 + k < slen) { issue_stage(st0 + it0 + k, (it0 + k) % NB); nissued = it0 + k + 1; }
             wait_direct_loads();                  // (nothing to wait for after the prologue)
             __syncthreads();
-            pipe.begin(lds + (it0 % NB) * SU, lane, qf);
+            if (wave_live) pipe.begin(lds + (it0 % NB) * SU, lane, qf);
             // The copies issued inside the loop go through running pointers (one per unit this wave
             // copies): a handful of scalar adds per stage instead of the full address arithmetic of
             // issue_stage -- scalar instructions cost issue slots the loop does not have to spare.
@@ -820,7 +830,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
             for (int it = it0; it < it1; ++it) {
                 const u32x4* L = lds + (it % NB) * SU;
                 const u32x4* Ln = lds + ((it + 1) % NB) * SU;
-                static_for<0, U - 1>([&](auto uc) { pipe.template slot<decltype(uc)::value>(L, Ln, lane, qf, O, rs); });
+                if (wave_live)
+                    static_for<0, U - 1>([&](auto uc) { pipe.template slot<decltype(uc)::value>(L, Ln, lane, qf, O, rs); });
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NL) : "memory");
                 __syncthreads();
                 // unconditional (no branch in the loop body): past the end the last stage is copied again
@@ -835,9 +846,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                         rp[i] += i < NKL ? stepk : stepv;
                     }
                 }
-                pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
+                if (wave_live) pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
             }
-            pipe.finish(O);
+            if (wave_live) pipe.finish(O);
             nissued = max(nissued, min(slen, it1 + NB));
         }
     };
@@ -935,6 +946,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
             __syncthreads();          // chunk c is visible; every wave is done with chunk c - 1
             issue_chunk(min(c + RC - 1, nchunk - 1), (c + RC - 1) % RC);
             const u32x4* L = lds + (c % RC) * CH * KU;
+            if (!wave_live) continue;
             if (c * CH + CH <= nfull_) {
 #pragma unroll
                 for (int j = 0; j < CH * KVS; ++j) {
@@ -1032,7 +1044,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
         if (pass == 0) {
             if (nfull > 0) {
                 // the reference: every row's largest logit over the first stage (logits only, no P.V)
-                {
+                if (wave_live) {
                     float m[QT];
 #pragma unroll
                     for (int t = 0; t < QT; ++t) m[t] = -SID_INF;

@@ -122,8 +122,8 @@ def test_flag_changes_nothing_that_matters(N, d, sigma, mask, compute, monkeypat
     qt = 2 if d <= 48 else 1                             # 32-query tiles per wave
     qwaves = -(-((N + 31) // 32) // qt)
     nw = 8 if qwaves >= 64 else 4                        # waves per workgroup
-    base = 2 * H * -(-qwaves // nw)                      # the second mask side starts a group of its own: up to one more
-    assert base <= groups <= base + 2 * H and dead <= groups and redone <= lo
+    base = 2 * H * -(-qwaves // nw)                      # mask sides start groups of their own: up to two more
+    assert base <= groups <= base + 2 * H * 2 and dead <= groups and redone <= lo
     if mask in ("halves", "disc", "random") and sigma >= 2.0:
         assert dead == groups                            # no group straddles two sides of a binary mask
     if mask == "soft" and sigma >= 2.0:
@@ -284,25 +284,33 @@ def test_with_the_throughput_decomposition():
     assert rel_err(skipped[1].cpu().numpy()[rows], oracle_rows(t, 1, rows, d)) < 3.5e-2
 
 
-def test_token_regrouping_matches_a_stable_partition():
+@pytest.mark.parametrize("B", [1, 2])
+def test_token_regrouping_matches_a_stable_partition(B):
     """White box: the token order the pack launch leaves in the workspace (4 counters, one group count per
-    head slot, then positions x images) against numpy: [m > thr | the rest | padding | m < -thr | padding] in
-    token order, thr = max(T * scale, 1/2), padded with -1 to whole workgroups of 512 queries."""
+    head slot, then positions x images) against numpy: [m > thr | the rest | m < -thr] in token order,
+    thr = max(T * scale, 1/2), padded with -1 to whole workgroups of 512 queries -- every side where the
+    launch is one round of workgroups, only the last side otherwise (the rest then rides behind the first)."""
+    import ctypes
     from style_transfer_amd import lib
-    N, d, B = 4096, 40, 2
+    N, d = 4096, 40
     t = inputs(7900, B, N, d, 3.0, "random")
     rng = np.random.default_rng(7901)
     m = np.where(rng.random((B, N)) < 0.3, 1.0, -1.0).astype(np.float32)
     m[0, rng.random(N) < 0.1] = 0.1                       # below the threshold: rides behind the first side
     m[0, rng.random(N) < 0.05] = -0.5                     # the blurred boundary of a +-1 mask: likewise
-    m[1, :] = 1.0                                           # a single side
+    if B > 1:
+        m[1, :] = 1.0                                       # a single side
     t["mask"] = torch.from_numpy(m).to("cuda:0")
     run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
     torch.cuda.synchronize()
     L = lib.load()
     off = L.sid_injected_attn_skip_counts_offset(B, H, N, d, lib.COMPUTE_BF16, 1, 0)
     ws = ops._workspaces[(0, torch.cuda.current_stream().cuda_stream)]
-    GR, groups_max = 512, N // 512 + 1
+    plan = (ctypes.c_int * 40)()
+    assert L.sid_attn_plan(3, B, H, N, N, d, lib.COMPUTE_BF16, 1, plan) == 0
+    own_middle = B * H * (plan[6] + 2) * plan[0] <= 256 * (1 if plan[4] == 8 else 2)
+    assert own_middle == (B == 1)
+    GR, groups_max = 512, N // 512 + 2
     NP = groups_max * GR
     goff = off + 256
     roff = goff + ((B * H * 4 + 255) // 256) * 256
@@ -310,7 +318,10 @@ def test_token_regrouping_matches_a_stable_partition():
     rowmap = ws[roff:roff + 4 * B * NP].view(torch.int32).cpu().numpy().reshape(B, NP)
     thr = max(1.5 * d ** -0.5, 0.5)
     for b in range(B):
-        want = list(np.nonzero(m[b] > thr)[0]) + list(np.nonzero(np.abs(m[b]) <= thr)[0])
+        want = list(np.nonzero(m[b] > thr)[0])
+        if own_middle:
+            want += [-1] * (-len(want) % GR)
+        want += list(np.nonzero(np.abs(m[b]) <= thr)[0])
         want += [-1] * (-len(want) % GR)
         far = list(np.nonzero(m[b] < -thr)[0])
         want += far + [-1] * (-len(far) % GR)

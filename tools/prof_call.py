@@ -1,7 +1,7 @@
 """The injected attention call as a feature store serves it (key/value pairs pre-packed), timed the way the
 path runs it: a HIP graph of back-to-back calls.  Prints the whole call (query pack + flash + merge) and
 the flash stage alone.
-    python tools/prof_call.py [N d B reps compute flags sigma mask]      mask: random | halves | disc"""
+    python tools/prof_call.py [N d B reps compute flags sigma mask]      mask: random | halves | disc | real:<name of a golden content mask>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,6 +24,11 @@ if len(sys.argv) > 8 and sys.argv[8] == "disc":
     from style_transfer_amd import synth
     side = int(round(N ** 0.5))
     m = (torch.from_numpy(synth.disc_mask(side, 0.3)).reshape(1, N) * 2 - 1).to(dev).repeat(B, 1).contiguous()
+if len(sys.argv) > 8 and sys.argv[8].startswith("real:"):      # one of the reference's content masks (tests/golden)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from helpers import load_masks
+    side = int(round(N ** 0.5))
+    m = ops.mask_downsample(torch.from_numpy(load_masks()[sys.argv[8][5:]]).to(dev), side, side, 1.0).reshape(1, N).repeat(B, 1).contiguous()
 out = torch.empty_like(xq)
 
 
