@@ -64,8 +64,8 @@ extern "C" {
  * Nothing is dropped on belief: results differ from the unflagged call only the way two decompositions of
  * one call differ (runs round their probabilities to bf16 against their own reference).
  * Takes effect with SID_COMPUTE_BF16 / F16QK, T > 0, scale > 0 and N >= 2048; elsewhere the flag is ignored.
- * Measured on (B,8,4096,40), a disc mask, features two to three times unit variance: 13-30 % less time
- * per call at B = 16 (a shared GPU), 8-15 % at one image; about 20-25 % MORE when no block can be dropped
+ * Measured on (B,8,4096,40), disc and real content masks, features two to three times unit variance:
+ * 15-33 % less time per call at B = 16 (a shared GPU), 7-12 % at one image; about 15-22 % MORE when no block can be dropped
  * (the regrouping pads every mask side to a whole workgroup, and the bounds cost a few microseconds), so
  * set it only for feature-sized logits.  sid_injected_attn_skip_counts_offset tells what was dropped. */
 #define SID_FLAG_BLOCK_SKIP 1
