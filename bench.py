@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (host UNet around the path)")
     ap.add_argument("--no-block-skip", action="store_true", help="skip the SID_FLAG_BLOCK_SKIP on/off record")
+    ap.add_argument("--no-content-cache", action="store_true", help="skip the cached-content-block record")
     ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
@@ -146,10 +147,14 @@ def make_image_workload(dev, gen, dtype, store, compute, sigma=1.0):
     return w
 
 
-def injected_call(layer, e, compute, flags=0):
+def injected_call(layer, e, compute, flags=0, cached=False):
+    """`cached`: take the content block from the partial attached to the content pair (content_cache_record)."""
     from style_transfer_amd import ops
     q_cnt, kv = layer["feats"][e]
     scale = layer["d"] ** -0.5
+    if cached:
+        return ops.injected_attention_cached(layer["xq"][e], q_cnt, kv[0], kv[1], kv[2].partial, layer["mask"], GAMMA, TEMP,
+                                             scale, HEADS, flags=flags)
     if isinstance(kv[0], ops.PackedKV):
         return ops.injected_attention_packed(layer["xq"][e], q_cnt, kv[0], kv[1], kv[2], layer["mask"], GAMMA, TEMP, scale,
                                              HEADS, flags=flags)
@@ -157,7 +162,7 @@ def injected_call(layer, e, compute, flags=0):
                                   layer["mask"], GAMMA, TEMP, scale, HEADS, compute=compute, flags=flags)
 
 
-def run_image(w, compute, flags=0):
+def run_image(w, compute, flags=0, cached=False):
     """The hot path of one image: the masked AdaIN initial latent, then 49 evaluations in UNet order."""
     from style_transfer_amd import ops
     from style_transfer_amd.attention import resolve_compute
@@ -173,7 +178,7 @@ def run_image(w, compute, flags=0):
             if hf_on:
                 m = w["hf"][li]
                 ops.hf_filter(m["h_cnt"][e - HF_FIRST], RATIO, skip=m["skip"], h=m["h"])
-            outs = injected_call(layer, e, compute, flags)
+            outs = injected_call(layer, e, compute, flags, cached)
     return outs
 
 
@@ -315,6 +320,81 @@ def block_skip_record(dev, compute):
                 rates[name] = images / (time.perf_counter() - t0)
     rec["image"] = {"what": "hot path of one image as in `value`, 3 images in flight, attention tensors x3 (feature-sized logits)",
                     "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"], "ratio": rates["on"] / rates["off"]}
+    del lanes
+    torch.cuda.empty_cache()
+    return rec
+
+
+def content_cache_record(dev, compute):
+    """The cached content block (sid_content_partial + sid_injected_attn_fwd_cached): the third key block of
+    the injected attention reads the content image's feature file only, so a content image that meets
+    several style pairs computes it once.  Call level at (B,8,4096,40), then the whole hot path of an image
+    with three images in flight, content blocks cached against computed.  Not part of `value`: the headline
+    is one content with one style pair and computes all three blocks in every call."""
+    import torch
+    from style_transfer_amd import ops
+    N, d = 4096, 40
+    gen = torch.Generator(device=dev); gen.manual_seed(5151)
+    rec = {"layer": "injected attention (B,8,4096,40), pre-packed key/value pairs, %s" % compute, "cases": []}
+    for B in (1, 16):
+        rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
+        xq, q_cnt = rn(B, N, HEADS * d), rn(B * HEADS, N, d)
+        kv = [ops.pack_kv(rn(B * HEADS, N, d), rn(B * HEADS, N, d), HEADS, compute) for _ in range(3)]
+        mask = torch.sign(rn(B, N)).contiguous()
+        out = torch.empty_like(xq)
+        partial = ops.content_partial(q_cnt, kv[2], d ** -0.5, HEADS)
+        reps = 200 if B == 1 else 20
+        t3 = events_per_call(lambda: ops.injected_attention_packed(xq, q_cnt, kv[0], kv[1], kv[2], mask, GAMMA, TEMP, d ** -0.5,
+                                                                   HEADS, out=out), reps)
+        t2 = events_per_call(lambda: ops.injected_attention_cached(xq, q_cnt, kv[0], kv[1], partial, mask, GAMMA, TEMP, d ** -0.5,
+                                                                   HEADS, out=out), reps)
+        tp = events_per_call(lambda: ops.content_partial(q_cnt, kv[2], d ** -0.5, HEADS), max(reps // 4, 5))
+        rec["cases"].append({"B": B, "call_ms_three_blocks": t3 * 1e3, "call_ms_content_cached": t2 * 1e3, "time_ratio": t2 / t3,
+                             "partial_ms": tp * 1e3, "flop_computed_per_call": 8.0 * B * HEADS * N * N * d})
+        del xq, q_cnt, kv, out, partial
+        torch.cuda.empty_cache()
+    n_lanes, images = 3, 12
+    lanes = []
+    t_partials = None
+    for li in range(n_lanes):
+        gen.manual_seed(5200 + li)
+        w = make_image_workload(dev, gen, torch.float32, "packed", compute)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        jobs = [(q_cnt, kv[2], layer["d"] ** -0.5) for layer in w["inj"] for q_cnt, kv in layer["feats"]]
+        for (_, kvc, _), partial in zip(jobs, ops.content_partials(jobs, HEADS)):      # four side streams
+            kvc.partial = partial
+        torch.cuda.synchronize()
+        t_partials = time.perf_counter() - t0
+        st = torch.cuda.Stream(device=dev)
+        graphs = {}
+        for name, cached in (("computed", False), ("cached", True)):
+            with torch.cuda.stream(st):
+                run_image(w, compute, ops.FLAG_THROUGHPUT, cached)
+            torch.cuda.synchronize()
+            graphs[name] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[name], stream=st, capture_error_mode="thread_local"):
+                run_image(w, compute, ops.FLAG_THROUGHPUT, cached)
+        lanes.append((st, graphs, w))
+    rates = {}
+    for name in ("computed", "cached"):
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(images):
+                st, graphs, _ = lanes[i % n_lanes]
+                with torch.cuda.stream(st):
+                    graphs[name].replay()
+            torch.cuda.synchronize()
+            if timed:
+                rates[name] = images / (time.perf_counter() - t0)
+    part_bytes = sum(kv[2].partial.nbytes() for layer in lanes[0][2]["inj"] for _, kv in layer["feats"])
+    rec["image"] = {"what": "hot path of one image as in `value`, 3 images in flight; `cached`: the content blocks of its 294 "
+                            "injected calls come from partials made once per content image",
+                    "imgs_per_s_content_computed": rates["computed"], "imgs_per_s_content_cached": rates["cached"],
+                    "ratio": rates["cached"] / rates["computed"],
+                    "partials_s_per_content_image": t_partials, "partials_GB_per_content_image": part_bytes / 1e9,
+                    "style_pairs_to_break_even": t_partials / max(1.0 / rates["computed"] - 1.0 / rates["cached"], 1e-9)}
     del lanes
     torch.cuda.empty_cache()
     return rec
@@ -579,11 +659,13 @@ def run_rank(args, world, rank, local):
             del lanes[1:]
             torch.cuda.empty_cache()
             line["block_skip"] = None if args.no_block_skip else block_skip_record(dev, args.compute)
+            line["content_cache"] = None if args.no_content_cache else content_cache_record(dev, args.compute)
             line["e2e"] = None if args.no_e2e else e2e_record(dev, args.compute, args.store)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         else:
             line["e2e"] = None
             line["block_skip"] = None
+            line["content_cache"] = None
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -148,6 +148,49 @@ int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Cached content block: the feature store's other side of the injected attention.
+ * The third key block of a call, softmax-partial of (q_cnt k_cnt^T)*scale over v_cnt
+ * (ldm/modules/attention.py:201-207 and the content third of :538-546), reads nothing but the content
+ * image's feature file: q_cnt, k_cnt, v_cnt of one (timestep, layer).  It does not depend on the latent,
+ * on the styles, on gamma or on T, so a content image that is stylised with several style pairs can
+ * have it computed once per (timestep, layer) and reused: a third of the call's matrix work.
+ * No counterpart in the reference, which recomputes it in every call.
+ *
+ *   sid_content_partial_bytes   size of the partial of one (q_cnt, k_cnt, v_cnt) triple
+ *   sid_content_partial         q_cnt (B*H, N, d) in `dtype` and the content pair's image (sid_pack_kv,
+ *                               same B, H, N, d, compute) -> partial (256-byte aligned, caller-owned):
+ *                               per (head, row) the block's normalised output row (halves; f32 with
+ *                               SID_COMPUTE_F32X3), its softmax reference and row sum, and the extremes
+ *                               of q_cnt.k_cnt that the mask bias needs.  Workspace:
+ *                               sid_content_partial_workspace_bytes.
+ *   sid_injected_attn_fwd_cached
+ *                               sid_injected_attn_fwd_packed with the content pair's image replaced by
+ *                               the partial made with the same B, H, N, d, compute, scale and q_cnt.
+ *                               Only the two style blocks are computed.  Results equal those of the
+ *                               other entry points the way two decompositions of one call are equal
+ *                               (each part rounds its probabilities against its own reference).
+ *                               SID_FLAG_BLOCK_SKIP is ignored.  Workspace:
+ *                               sid_injected_attn_cached_workspace_bytes.
+ */
+size_t sid_content_partial_bytes(int B, int H, int N, int d, int compute);
+
+size_t sid_content_partial_workspace_bytes(int B, int H, int N, int d, int compute);
+
+int sid_content_partial(const void* q_cnt, const void* kv_cnt_image, void* partial, size_t partial_bytes,
+                        int B, int H, int N, int d, float scale, int dtype, int compute,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+size_t sid_injected_attn_cached_workspace_bytes(int B, int H, int N, int d, int compute);
+
+int sid_injected_attn_fwd_cached(const void* x_q, const void* q_cnt,
+                                 const void* kv1_image, const void* kv2_image, const void* content_partial,
+                                 const float* mask_signed, void* out,
+                                 int B, int H, int N, int d,
+                                 float gamma, float q_self_coef, float T, float scale,
+                                 int dtype, int compute, int flags,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * sid_injected_attn_fwd for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments and results as sid_injected_attn_fwd without the workspace pair: the scratch is a

@@ -134,6 +134,14 @@ class CrossAttention(nn.Module):
                 q_cnt = self._as(q_injected, xq)
                 self.k, self.v = k_injected, v_injected
                 self._q, self._q_lazy = None, (lambda: q_cnt * gamma + self._split(xq) * (1. - 0.5))
+                partial = getattr(cnt_k_injected, "partial", None)
+                if partial is not None and partial.q_ptr == q_cnt.data_ptr() and partial.scale == float(self.scale):
+                    # the store computed the content block of this (timestep, layer) when it was loaded
+                    # (FeatureStore.pack(cache_content=True)): only the two style blocks are left
+                    out = ops.injected_attention_cached(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, partial, m,
+                                                        gamma, T, self.scale, self.heads, q_self_coef=0.5,
+                                                        flags=self.kernel_flags & ~ops.FLAG_BLOCK_SKIP)
+                    return self.to_out(out)
                 out = ops.injected_attention_packed(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, cnt_k_injected, m,
                                                     gamma, T, self.scale, self.heads, q_self_coef=0.5,
                                                     flags=self.kernel_flags)

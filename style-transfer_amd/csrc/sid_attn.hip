@@ -512,6 +512,17 @@ void carve_kv(const Geometry& g, bool x3, const void* base, KvImage* im) {
     im->bytes = off;
 }
 
+// A cached content block (sid_content_partial): one partial slot kept by the caller,
+// [rows x d output rows: halves, f32 in the f32-grade mode | rows x 4 f32 statistics], rows = B*H*N.
+struct PartialImage { void* rows; float* stats; size_t bytes; };
+void carve_partial(long long rows, int d, bool x3, const void* base, PartialImage* im) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += sid::align_up(bytes, 256); return p; };
+    im->rows = take((size_t)rows * d * (x3 ? 4 : 2));
+    im->stats = (float*)take((size_t)rows * 16);
+    im->bytes = off;
+}
+
 // element strides {batch, head, token} of a layout
 void layout_strides(int layout, int H, int N, int d, long long s[3]) {
     if (layout == SID_LAYOUT_BHND) { s[0] = (long long)H * N * d; s[1] = (long long)N * d; s[2] = d; }
@@ -570,9 +581,11 @@ int check_common(int B, int H, int Nq, int Nk, int d, int dtype, int compute) {
 }
 
 // flash + merge stages shared by the two entry points
+// `keep_partial`: the call ends with its partial slots (a content block computed for later calls): nothing
+// is normalised or merged.  `cached`: the content block of an injected call comes from such a partial.
 int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, const Stages& stg, const float* mask,
                     void* out, float scale, int B, int H, int Nq, int Nk, int d, int nblk, int dtype, bool x3,
-                    hipStream_t stream, bool qk16 = false) {
+                    hipStream_t stream, bool qk16 = false, bool keep_partial = false, const PartialImage* cached = nullptr) {
     fp.opart = w.opart; fp.stats = w.stats; fp.out = out;
     fp.part_f16 = !x3;
     fp.B = B; fp.H = H; fp.Nq = Nq; fp.Nk = Nk; fp.d = d; fp.NQT = g.NQT; fp.NKT = g.NKT;
@@ -580,7 +593,7 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
     fp.KS = g.KS; fp.SPB = g.SPB; fp.W = g.W; fp.nblk = nblk;
     for (int k = 0; k <= g.W; ++k) fp.bound[k] = g.bound[k];
     for (int b = 0; b < kBlocks; ++b) { fp.first_run[b] = g.first_run[b]; fp.nseg[b] = g.nseg[b]; }
-    fp.direct = nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
+    fp.direct = !keep_partial && nblk * g.KS == 1; fp.out_bf16 = dtype == SID_DTYPE_BF16;
 #ifdef SID_DIAG
     fp.diag = (unsigned long long*)(getenv("SID_DIAG_PTR") ? strtoull(getenv("SID_DIAG_PTR"), nullptr, 0) : 0ull);
 #endif
@@ -589,8 +602,9 @@ int run_flash_merge(FlashParams& fp, const Geometry& g, const Workspace& w, cons
                           : (qk16 ? launch_flash_f16qk(fp, g, stream) : launch_flash_bf16(fp, g, stream));
         if (rc != SID_OK) return rc;
     }
-    if (!stg.merge || fp.direct) return SID_OK;
+    if (!stg.merge || fp.direct || keep_partial) return SID_OK;
     MergeParams mp = {};
+    if (cached) { mp.cpart = cached->rows; mp.cstats = cached->stats; }
     mp.opart = w.opart; mp.stats = w.stats; mp.mask = mask; mp.out = out; mp.scale = scale;
     mp.part_f16 = fp.part_f16;
     for (int b = 0; b < kBlocks; ++b) mp.c2[b] = fp.c2[b];
@@ -874,6 +888,175 @@ extern "C" int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt, 
                               (hipStream_t)stream, images);
 }
 
+// ---- cached content block ---------------------------------------------------------------------------
+extern "C" size_t sid_content_partial_bytes(int B, int H, int N, int d, int compute) {
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    PartialImage im;
+    carve_partial((long long)B * H * N, d, compute == SID_COMPUTE_F32X3, nullptr, &im);
+    return im.bytes;
+}
+
+namespace {
+// the content block alone: one run per (head, query group), so that it fills exactly one partial slot
+int content_geometry(int B, int H, int N, int d, bool x3, Geometry* g) {
+    const int rc = make_geometry(B, H, N, N, d, 1, x3, true, g);
+    if (rc != SID_OK) return rc;
+    if (g->W != 1 || g->KS != 1)
+        return sid::fail(SID_EINVAL, "the content partial is one run per head (SID_TUNE_W / SID_TUNE_KS must not be set)");
+    return SID_OK;
+}
+}  // namespace
+
+extern "C" size_t sid_content_partial_workspace_bytes(int B, int H, int N, int d, int compute) {
+    Geometry g;
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    if (content_geometry(B, H, N, d, x3, &g) != SID_OK) return 0;
+    Workspace w;
+    carve(g, 1, 1, x3, (long long)B * H * N, d, nullptr, &w, false);
+    return w.bytes;
+}
+
+extern "C" int sid_content_partial(const void* q_cnt, const void* kv_cnt_image, void* partial, size_t partial_bytes,
+                                   int B, int H, int N, int d, float scale, int dtype, int compute,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_common(B, H, N, N, d, dtype, compute);
+    if (rc != SID_OK) return rc;
+    SID_CHECK_ARG(q_cnt && kv_cnt_image && partial, "NULL tensor pointer");
+    SID_CHECK_ARG(((uintptr_t)kv_cnt_image & 255) == 0 && ((uintptr_t)partial & 255) == 0,
+                  "the K/V image and the partial must be 256-byte aligned");
+    SID_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace must be non-NULL and 256-byte aligned");
+    SID_CHECK_ARG(std::isfinite(scale), "scale must be finite");
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    Geometry g;
+    rc = content_geometry(B, H, N, d, x3, &g);
+    if (rc != SID_OK) return rc;
+    const long long rows = (long long)B * H * N;
+    PartialImage im;
+    carve_partial(rows, d, x3, partial, &im);
+    if (im.bytes > partial_bytes)
+        return sid::fail(SID_ENOMEM, "partial of %zu bytes is smaller than the %zu required", partial_bytes, im.bytes);
+    Workspace w;
+    carve(g, 1, 1, x3, rows, d, workspace, &w, false);
+    if (w.bytes > workspace_bytes)
+        return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
+    KvImage kim;
+    carve_kv(g, x3, kv_cnt_image, &kim);
+    const float c2c = clamp_scale(scale * LOG2E);
+    const bool qk16 = compute == SID_COMPUTE_F16QK;
+    if (qk16) {
+        rc = check_f16qk(g.DKS, g.DVB, d, &c2c, 1);
+        if (rc != SID_OK) return rc;
+    }
+    PackParams pp = {};
+    pp.njobs = 1; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+    pp.f16_rows = qk16;
+    long long frags[kMaxJobs];
+    {
+        PackJob& j = pp.job[0];
+        j = PackJob{};
+        j.src = q_cnt; j.dst = w.q[0][0]; j.dst_lo = w.q[0][1]; j.kind = 0; j.N = N; j.NT = g.NQT;
+        j.post = c2c; j.ones_at = -1;
+        set_strides(j, SID_LAYOUT_BHND, H, N, d, false);
+        frags[0] = (long long)g.q_units;
+    }
+    rc = launch_pack(pp, frags, stream);
+    if (rc != SID_OK) return rc;
+    FlashParams fp = {};
+    fp.shift_cols = has_shift_cols(d, g.DKS);
+    fp.q[0] = w.q[0][0]; fp.q_lo[0] = w.q[0][1];
+    fp.k[0] = kim.k[0]; fp.k_lo[0] = kim.k[1];
+    fp.v[0] = kim.v[0]; fp.v_lo[0] = kim.v[1];
+    fp.c2[0] = c2c;
+    fp.content_only = 1;
+    Workspace wp = w;               // the one partial slot of the call is the caller's buffer
+    wp.opart = (float*)im.rows; wp.stats = im.stats;
+    return run_flash_merge(fp, g, wp, Stages(0), nullptr, nullptr, scale, B, H, N, N, d, 1, dtype, x3, stream, qk16, true);
+}
+
+extern "C" size_t sid_injected_attn_cached_workspace_bytes(int B, int H, int N, int d, int compute) {
+    Geometry g;
+    if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    size_t bytes = 0;
+    for (int thr = 0; thr < 2; ++thr) {
+        if (make_geometry(B, H, N, N, d, 2, x3, thr != 0, &g) != SID_OK) return 0;
+        Workspace w;
+        carve(g, 2, 1, x3, (long long)B * H * N, d, nullptr, &w, false);
+        bytes = std::max(bytes, w.bytes);
+    }
+    return bytes;
+}
+
+extern "C" int sid_injected_attn_fwd_cached(const void* x_q, const void* q_cnt, const void* kv1_image,
+                                            const void* kv2_image, const void* content_partial,
+                                            const float* mask_signed, void* out, int B, int H, int N, int d,
+                                            float gamma, float q_self_coef, float T, float scale, int dtype,
+                                            int compute, int flags, void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const Stages stg(flags);
+    int rc = check_common(B, H, N, N, d, dtype, compute);
+    if (rc != SID_OK) return rc;
+    SID_CHECK_ARG(x_q && q_cnt && kv1_image && kv2_image && content_partial && mask_signed && out, "NULL tensor pointer");
+    SID_CHECK_ARG(((uintptr_t)kv1_image & 255) == 0 && ((uintptr_t)kv2_image & 255) == 0 && ((uintptr_t)content_partial & 255) == 0,
+                  "K/V images and the content partial must be 256-byte aligned");
+    SID_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace must be non-NULL and 256-byte aligned");
+    SID_CHECK_ARG(((uintptr_t)out & 15) == 0, "out must be 16-byte aligned");
+    SID_CHECK_ARG(std::isfinite(gamma) && std::isfinite(q_self_coef) && std::isfinite(T) && std::isfinite(scale),
+                  "gamma, q_self_coef, T and scale must be finite");
+    const bool x3 = compute == SID_COMPUTE_F32X3;
+    Geometry g;
+    rc = make_geometry(B, H, N, N, d, 2, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
+    if (rc != SID_OK) return rc;
+    const long long rows = (long long)B * H * N;
+    Workspace w;
+    carve(g, 2, 1, x3, rows, d, workspace, &w, false);
+    if (w.bytes > workspace_bytes)
+        return sid::fail(SID_ENOMEM, "workspace of %zu bytes is smaller than the %zu required", workspace_bytes, w.bytes);
+    const void* images[2] = {kv1_image, kv2_image};
+    for (int b = 0; b < 2; ++b) {
+        KvImage im;
+        carve_kv(g, x3, images[b], &im);
+        for (int p = 0; p < 2; ++p) { w.k[b][p] = im.k[p]; w.v[b][p] = im.v[p]; }
+    }
+    PartialImage cached;
+    carve_partial(rows, d, x3, content_partial, &cached);
+    const float c2s = clamp_scale(T * scale * LOG2E), c2c = clamp_scale(scale * LOG2E);
+    const bool qk16 = compute == SID_COMPUTE_F16QK;
+    if (qk16) {
+        rc = check_f16qk(g.DKS, g.DVB, d, &c2s, 1);
+        if (rc != SID_OK) return rc;
+    }
+    if (stg.pack) {                 // the blended query is the only image a call makes
+        PackParams pp = {};
+        pp.njobs = 1; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
+        pp.f16_rows = qk16;
+        long long frags[kMaxJobs];
+        PackJob& j = pp.job[0];
+        j = PackJob{};
+        j.src = q_cnt; j.dst = w.q[0][0]; j.dst_lo = w.q[0][1]; j.kind = 0; j.N = N; j.NT = g.NQT;
+        j.ones_at = -1;
+        set_strides(j, SID_LAYOUT_BHND, H, N, d, false);
+        j.src2 = x_q; j.c1 = gamma; j.c2 = q_self_coef; j.post = c2s;
+        set_strides(j, SID_LAYOUT_BNHD, H, N, d, true);
+        frags[0] = (long long)g.q_units;
+        rc = launch_pack(pp, frags, stream);
+        if (rc != SID_OK) return rc;
+    }
+    FlashParams fp = {};
+    fp.shift_cols = has_shift_cols(d, g.DKS);
+    for (int b = 0; b < 2; ++b) {
+        fp.q[b] = w.q[0][0]; fp.q_lo[b] = w.q[0][1];
+        fp.k[b] = w.k[b][0]; fp.k_lo[b] = w.k[b][1];
+        fp.v[b] = w.v[b][0]; fp.v_lo[b] = w.v[b][1];
+    }
+    fp.c2[0] = fp.c2[1] = c2s;
+    fp.c2[2] = c2c;
+    return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, 2, dtype, x3, stream, qk16, false, &cached);
+}
+
 extern "C" long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int compute, int flags, int packed) {
     Geometry g;
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return -1;
@@ -997,7 +1180,9 @@ namespace sid_attn {
 // at compile time: all statistics and all partial rows are then requested before the first one is
 // used (one memory round trip per thread instead of one per part).
 // PART16: the partial rows are halves, normalised by their row sum (a part then weighs w * l).
-template <int VEC, int NP, bool PART16>
+// CACHED: the call computed the two style blocks (nblk == 2); the content block is one more part, the
+// last one, read from a partial kept outside the workspace (P.cpart / P.cstats).
+template <int VEC, int NP, bool PART16, bool CACHED>
 __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const int dpv = P.d / VEC;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1009,15 +1194,19 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     const int bh = (int)(t / P.Nq);
     const int b = bh / P.H, h = bh % P.H;
     const int BH = P.B * P.H;
-    const int nparts = NP > 0 ? NP : P.nblk * P.KS;
+    const int nparts = NP > 0 ? NP : P.nblk * P.KS + (CACHED ? 1 : 0);
     constexpr int CAP = NP > 0 ? NP : 1;
     constexpr float LOG2E = 1.4426950408889634f;
-    auto stat_ptr = [&](int p) { return (const f32x4*)(P.stats + (((size_t)p * BH + bh) * P.Nq + q) * 4); };
+    auto cached_part = [&](int p) { return CACHED && p == nparts - 1; };
+    auto stat_ptr = [&](int p) {
+        const float* base = cached_part(p) ? P.cstats : P.stats + (size_t)p * BH * P.Nq * 4;
+        return (const f32x4*)(base + ((size_t)bh * P.Nq + q) * 4);
+    };
     const size_t part_off = ((size_t)bh * P.Nq + q) * P.d + c * VEC, part_stride = (size_t)BH * P.Nq * P.d;
     // VEC values of part p as floats
     auto load_part = [&](int p, float (&o)[VEC]) {
         if (PART16) {
-            const _Float16* hp = (const _Float16*)P.opart + p * part_stride + part_off;
+            const _Float16* hp = (cached_part(p) ? (const _Float16*)P.cpart : (const _Float16*)P.opart + p * part_stride) + part_off;
             if (VEC == 4) {
                 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
                 const f16x4 v = *(const f16x4*)hp;
@@ -1027,7 +1216,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
                 o[0] = (float)hp[0];
             }
         } else {
-            const float* fp = P.opart + p * part_stride + part_off;
+            const float* fp = (cached_part(p) ? (const float*)P.cpart : P.opart + p * part_stride) + part_off;
             if (VEC == 4) {
                 const f32x4 v = *(const f32x4*)fp;
 #pragma unroll
@@ -1049,15 +1238,17 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
     auto stat = [&](int p) { return NP > 0 ? st_[NP > 0 ? p : 0] : *stat_ptr(p); };
 
     float bias2[kBlocks] = {0.f, 0.f, 0.f};
-    if (P.nblk == kBlocks) {
-        const int KS = nparts >= kBlocks ? nparts / kBlocks : 1;
+    if (P.nblk == kBlocks || CACHED) {
+        // parts per block: the workspace holds kBlocks blocks, or (CACHED) the two style blocks
+        const int KS = CACHED ? (nparts - 1) / 2 : (nparts >= kBlocks ? nparts / kBlocks : 1);
         float bmax[kBlocks], cmin = SID_INF;
 #pragma unroll
         for (int blk = 0; blk < kBlocks; ++blk) bmax[blk] = -SID_INF;
         if (NP > 0) {
 #pragma unroll
             for (int p = 0; p < CAP; ++p) {
-                const int blk = p / (CAP / kBlocks > 0 ? CAP / kBlocks : 1);
+                constexpr int KSC = CACHED ? (CAP > 2 ? (CAP - 1) / 2 : 1) : (CAP / kBlocks > 0 ? CAP / kBlocks : 1);
+                const int blk = (CACHED && p == CAP - 1) ? kBlocks - 1 : p / KSC;
                 const f32x4 st = stat(p);
 #pragma unroll
                 for (int k = 0; k < kBlocks; ++k) bmax[k] = (k == blk) ? fmaxf(bmax[k], st[2]) : bmax[k];
@@ -1065,7 +1256,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
             }
         } else {
             for (int p = 0; p < nparts; ++p) {
-                const int blk = p / KS;
+                const int blk = cached_part(p) ? kBlocks - 1 : p / KS;
                 const f32x4 st = stat(p);
 #pragma unroll
                 for (int k = 0; k < kBlocks; ++k) bmax[k] = (k == blk) ? fmaxf(bmax[k], st[2]) : bmax[k];
@@ -1079,7 +1270,7 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
         bias2[1] = __fmul_rn(__fsub_rn(min_cc, bmax[1]), __fmul_rn(m, 1.0f)) * LOG2E;
     }
     const int KSr = P.KS;
-    auto blk_of = [&](int p) { return p / KSr; };
+    auto blk_of = [&](int p) { return cached_part(p) ? kBlocks - 1 : p / KSr; };
     auto bias_of = [&](int p) { const int k = blk_of(p); return k == 0 ? bias2[0] : (k == 1 ? bias2[1] : bias2[2]); };
     // reference of the combined softmax: the largest log2 of a part's biased weight sum, m2 + log2(l)
     // (not the parts' own references m2, which a logit may exceed by up to 2^kOverflowThr)
@@ -1141,14 +1332,23 @@ __global__ void __launch_bounds__(256) merge_kernel(MergeParams P) {
 
 template <int VEC, bool PART16>
 void launch_merge_np(const MergeParams& mp, unsigned blocks, hipStream_t stream) {
+    if (mp.cpart) {                 // two style blocks in the workspace + the cached content part
+        switch (mp.nblk * mp.KS + 1) {
+            case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3, PART16, true>), dim3(blocks), dim3(256), 0, stream, mp); break;
+            case 5: hipLaunchKernelGGL((merge_kernel<VEC, 5, PART16, true>), dim3(blocks), dim3(256), 0, stream, mp); break;
+            case 7: hipLaunchKernelGGL((merge_kernel<VEC, 7, PART16, true>), dim3(blocks), dim3(256), 0, stream, mp); break;
+            default: hipLaunchKernelGGL((merge_kernel<VEC, 0, PART16, true>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        }
+        return;
+    }
     switch (mp.nblk * mp.KS) {
-        case 2: hipLaunchKernelGGL((merge_kernel<VEC, 2, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 9: hipLaunchKernelGGL((merge_kernel<VEC, 9, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        case 12: hipLaunchKernelGGL((merge_kernel<VEC, 12, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
-        default: hipLaunchKernelGGL((merge_kernel<VEC, 0, PART16>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 2: hipLaunchKernelGGL((merge_kernel<VEC, 2, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 3: hipLaunchKernelGGL((merge_kernel<VEC, 3, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 4: hipLaunchKernelGGL((merge_kernel<VEC, 4, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 6: hipLaunchKernelGGL((merge_kernel<VEC, 6, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 9: hipLaunchKernelGGL((merge_kernel<VEC, 9, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        case 12: hipLaunchKernelGGL((merge_kernel<VEC, 12, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
+        default: hipLaunchKernelGGL((merge_kernel<VEC, 0, PART16, false>), dim3(blocks), dim3(256), 0, stream, mp); break;
     }
 }
 

@@ -84,7 +84,10 @@ struct FlashParams {
     float ts, dead_gap;
     unsigned short bound2[kMaxRuns + 1];
     unsigned char first_run2[2], nseg2[2];
-    int nblk;                    // 3: injected [char | back | content], 1: single block
+    int nblk;                    // 3: injected [char | back | content], 2: the style blocks alone (the content
+                                 // block comes from a cached partial), 1: single block
+    int content_only;            // nblk == 1 and the block is a content block whose partial is kept: its smallest
+                                 // raw q.k is the extreme the mask bias needs, as in the third block of an injected call
     int direct;                  // single part: normalise and write `out` here, no merge kernel
     int out_bf16;
 #ifdef SID_DIAG
@@ -102,6 +105,10 @@ struct MergeParams {
     float c2[kBlocks];
     int B, H, Nq, d, KS, nblk;
     int out_bf16;
+    // cached content block (nblk == 2): one more part, [BH][Nq][d] rows and [BH][Nq][4] statistics in the
+    // layout of one partial slot, kept outside the workspace; null otherwise
+    const void* cpart;
+    const float* cstats;
 };
 
 // Launch geometry chosen on the host (make_geometry in sid_attn.hip).
@@ -907,7 +914,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
     part = blk * P.KS + (run_w - first_run);
     if (!prefetched) enter_block(blk);
     c2 = P.c2[blk];
-    need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || c2 < 0.f;
+    need_min = (P.nblk == kBlocks && blk == kBlocks - 1) || P.content_only || c2 < 0.f;
 
     // ---- block skipping, content block predicted dead for the whole query group: only the extremes of
     // its logits are needed (the mask bias takes min cc exactly), then the exact segment maximum is checked

@@ -145,10 +145,12 @@ class FeatureStore:
         self.cnt, self.char, self.back = cnt, char, back
 
     @classmethod
-    def load(cls, precomputed_dir, cnt_base, char_base, back_base, device="cuda", dtype=None):
+    def load(cls, precomputed_dir, cnt_base, char_base, back_base, device="cuda", dtype=None, cnt=None):
+        """`cnt`: the content list of an earlier triple with the same content image, as that triple's store
+        left it (loaded, possibly packed and carrying its cached content blocks), instead of the file."""
         import os
         rd = lambda name: load_feature_file(os.path.join(precomputed_dir, name), device, dtype)
-        return cls(rd(cnt_base + "_cnt.pkl"), rd(char_base + "_sty.pkl"), rd(back_base + "_sty.pkl"))
+        return cls(rd(cnt_base + "_cnt.pkl") if cnt is None else cnt, rd(char_base + "_sty.pkl"), rd(back_base + "_sty.pkl"))
 
     def z_enc(self):
         """The fully inverted latents (entry 0), cloned as run_ori.py:172,191,210 does."""
@@ -158,13 +160,18 @@ class FeatureStore:
         from .features import feat_merge_2sty
         return feat_merge_2sty(opt, self.cnt, self.char, self.back, start_step=start_step)
 
-    def pack(self, heads=8, compute="bf16"):
+    def pack(self, heads=8, compute="bf16", cache_content=False):
         """Convert every key/value pair of the three lists to the attention kernels' operand layout
         (ops.pack_kv), in place: `..._self_attn_k` and `..._self_attn_v` of a block then hold ONE
         PackedKV object and the two tensors are dropped.  Done once per feature file, it removes the
         per-call conversion of the six K/V tensors from the 49 x 6 attention calls of an image and
         shrinks the store (bf16 operands: 112 bytes per token and head at head_dim 40, against 320
-        for the two fp32 tensors).  The queries stay tensors: the kernel blends them per call."""
+        for the two fp32 tensors).  The queries stay tensors: the kernel blends them per call.
+        cache_content: also compute the content block of every (timestep, layer) of the content list
+        (ops.content_partial: it reads q, k, v of the content file only) and attach it to the content
+        pair; the attention calls then compute the two style blocks alone.  Worth it when the content
+        list is reused for several style pairs (pass it to the next FeatureStore.load as `cnt`): the
+        partials cost what one image's content blocks cost, 0.66 GB per content image at SD-v1 sizes."""
         from . import ops
         for feats in (self.cnt, self.char, self.back):
             for entry in feats:
@@ -175,6 +182,17 @@ class FeatureStore:
                     mode = "bf16" if compute == "f16" and not (33 <= d <= 48 or 65 <= d <= 80) else compute
                     kv = ops.pack_kv(entry[key].contiguous(), entry[vkey].contiguous(), heads, mode)
                     entry[key] = entry[vkey] = kv
+        if cache_content:
+            jobs = []
+            for entry in self.cnt:
+                for key in [k for k in entry if k.endswith("_self_attn_k") and isinstance(entry[k], ops.PackedKV)]:
+                    kv, qkey = entry[key], key[:-1] + "q"
+                    if kv.partial is None:
+                        # the partial remembers the tensor it was made from: the call must pass this very one
+                        q = entry[qkey] = entry[qkey].contiguous()
+                        jobs.append((q, kv, q.shape[-1] ** -0.5))
+            for (_, kv, _), partial in zip(jobs, ops.content_partials(jobs, heads)):
+                kv.partial = partial
         return self
 
     def nbytes(self):
@@ -186,5 +204,5 @@ class FeatureStore:
                         total += v.numel() * v.element_size()
                     elif hasattr(v, "image") and id(v) not in seen:
                         seen.add(id(v))
-                        total += v.nbytes()
+                        total += v.nbytes() + (v.partial.nbytes() if v.partial is not None else 0)
         return total

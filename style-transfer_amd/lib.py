@@ -29,6 +29,11 @@ SIGNATURES = {
     "sid_pack_kv": (_i, [_vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "sid_injected_attn_packed_workspace_bytes": (_sz, [_i] * 5),
     "sid_injected_attn_fwd_packed": (_i, [_vp] * 5 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
+    "sid_content_partial_bytes": (_sz, [_i] * 5),
+    "sid_content_partial_workspace_bytes": (_sz, [_i] * 5),
+    "sid_content_partial": (_i, [_vp, _vp, _vp, _sz] + [_i] * 4 + [_f] + [_i] * 2 + [_vp, _sz, _vp]),
+    "sid_injected_attn_cached_workspace_bytes": (_sz, [_i] * 5),
+    "sid_injected_attn_fwd_cached": (_i, [_vp] * 5 + [_vp, _vp] + [_i] * 4 + [_f] * 4 + [_i] * 3 + [_vp, _sz, _vp]),
     "sid_injected_attn_skip_counts_offset": (_c.c_longlong, [_i] * 7),
     "sid_attn_plan": (_i, [_i] * 8 + [_c.POINTER(_c.c_int)]),
     "sid_plain_attn_workspace_bytes": (_sz, [_i] * 6),

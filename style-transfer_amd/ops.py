@@ -136,6 +136,7 @@ class PackedKV:
 
     def __init__(self, image, B, H, N, d, compute):
         self.image, self.B, self.H, self.N, self.d, self.compute = image, B, H, N, d, compute
+        self.partial = None     # a content pair may carry its cached content block (ContentPartial)
 
     @property
     def device(self):
@@ -190,6 +191,101 @@ def injected_attention_packed(x_q, q_cnt, kv1, kv2, kv_cnt, mask_signed, gamma, 
     with torch.cuda.device(dev):
         _lib.check(L.sid_injected_attn_fwd_packed(
             x_q.data_ptr(), q_cnt.data_ptr(), kv1.image.data_ptr(), kv2.image.data_ptr(), kv_cnt.image.data_ptr(),
+            mask_signed.data_ptr(), out.data_ptr(), B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale),
+            _dtype_code(x_q), cc, int(flags), ws.data_ptr(), ws.numel(), _stream(dev)))
+    return out
+
+
+class ContentPartial:
+    """The content block of the injected attention for one (timestep, layer) of a content feature file
+    (sid_content_partial): per (head, row) the block's normalised output row, softmax reference and row
+    sum, and the q_cnt.k_cnt extremes the mask bias needs.  It depends on q_cnt, k_cnt, v_cnt and `scale`
+    only, so one content image stylised with several style pairs computes it once."""
+
+    def __init__(self, data, B, H, N, d, compute, scale, q_ptr):
+        self.data, self.B, self.H, self.N, self.d, self.compute, self.scale = data, B, H, N, d, compute, scale
+        self.q_ptr = q_ptr          # address of the q_cnt tensor it was made from (calls check they pass the same one)
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def nbytes(self):
+        return self.data.numel()
+
+
+def content_partial(q_cnt, kv_cnt, scale, heads):
+    """q_cnt (B*H, N, d) and the content pair's PackedKV -> ContentPartial (two launches on the current stream)."""
+    L = _lib.load()
+    dev = _need_cuda(q_cnt, kv_cnt.image)
+    B, H, N, d, cc = kv_cnt.B, kv_cnt.H, kv_cnt.N, kv_cnt.d, kv_cnt.compute
+    if H != heads or tuple(q_cnt.shape) != (B * H, N, d):
+        raise ValueError("q_cnt must be (B*H, N, d) = %s, got %s" % ((B * H, N, d), tuple(q_cnt.shape)))
+    nbytes = L.sid_content_partial_bytes(B, H, N, d, cc)
+    wbytes = L.sid_content_partial_workspace_bytes(B, H, N, d, cc)
+    if nbytes == 0 or wbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    data = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, wbytes)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_content_partial(q_cnt.data_ptr(), kv_cnt.image.data_ptr(), data.data_ptr(), nbytes, B, H, N, d,
+                                         float(scale), _dtype_code(q_cnt), cc, ws.data_ptr(), ws.numel(), _stream(dev)))
+    return ContentPartial(data, B, H, N, d, cc, float(scale), q_cnt.data_ptr())
+
+
+def content_partials(jobs, heads, streams=4):
+    """ContentPartial of every (q_cnt, PackedKV, scale) in `jobs`, in order.  One call is one run per (head,
+    query group), 64 workgroups at SD-v1 sizes, a quarter of the GPU, so the calls go round-robin over
+    `streams` side streams (each with its own workspace) and the current stream waits for all of them."""
+    if not jobs:
+        return []
+    dev = jobs[0][0].device
+    cur = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(streams, len(jobs))))]
+    out = []
+    for st in side:
+        st.wait_stream(cur)
+    for i, (q_cnt, kv, scale) in enumerate(jobs):
+        with torch.cuda.stream(side[i % len(side)]):
+            out.append(content_partial(q_cnt, kv, scale, heads))
+    for st in side:
+        cur.wait_stream(st)
+    for p in out:                       # made on a side stream, used on this one from here on
+        p.data.record_stream(cur)
+    return out
+
+
+def injected_attention_cached(x_q, q_cnt, kv1, kv2, partial, mask_signed, gamma, T, scale, heads, q_self_coef=0.5,
+                              out=None, flags=0):
+    """injected_attention_packed with the content pair replaced by its ContentPartial: only the two style
+    blocks are computed.  `scale` and `q_cnt` must be the ones the partial was made with."""
+    L = _lib.load()
+    B, N, C = x_q.shape
+    H = heads
+    d = C // H
+    dev = _need_cuda(x_q, q_cnt, mask_signed, kv1.image, kv2.image, partial.data)
+    if tuple(q_cnt.shape) != (B * H, N, d) or q_cnt.dtype != x_q.dtype:
+        raise ValueError("q_cnt must be (B*H, N, d) = %s of x_q's dtype" % ((B * H, N, d),))
+    cc = kv1.compute
+    for kv in (kv1, kv2, partial):
+        if (kv.B, kv.H, kv.N, kv.d, kv.compute) != (B, H, N, d, cc):
+            raise ValueError("packed K/V or content partial was made for (B,H,N,d,compute) = %s, the call has %s"
+                             % ((kv.B, kv.H, kv.N, kv.d, kv.compute), (B, H, N, d, cc)))
+    if partial.scale != float(scale):
+        raise ValueError("the content partial was made with scale %r, the call has %r" % (partial.scale, float(scale)))
+    if partial.q_ptr != q_cnt.data_ptr():
+        raise ValueError("the content partial was made from another q_cnt tensor")
+    if mask_signed.dtype != torch.float32 or mask_signed.numel() != B * N:
+        raise ValueError("mask_signed must be float32 with B*N elements")
+    if out is None:
+        out = torch.empty((B, N, C), dtype=x_q.dtype, device=dev)
+    nbytes = L.sid_injected_attn_cached_workspace_bytes(B, H, N, d, cc)
+    if nbytes == 0:
+        raise _lib.SidError(-22, L.sid_last_error().decode())
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_injected_attn_fwd_cached(
+            x_q.data_ptr(), q_cnt.data_ptr(), kv1.image.data_ptr(), kv2.image.data_ptr(), partial.data.data_ptr(),
             mask_signed.data_ptr(), out.data_ptr(), B, H, N, d, float(gamma), float(q_self_coef), float(T), float(scale),
             _dtype_code(x_q), cc, int(flags), ws.data_ptr(), ws.numel(), _stream(dev)))
     return out

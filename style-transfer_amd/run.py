@@ -61,6 +61,10 @@ def build_parser():
     p.add_argument('--block_skip', action='store_true',
                    help="injected attention leaves out key blocks whose softmax mass is provably nil (SID_FLAG_BLOCK_SKIP); "
                         "every layer keeps the flag for an image only if its first call dropped something")
+    p.add_argument('--cache_content', action='store_true',
+                   help="compute the content block of the injected attention once per content image (when its features are "
+                        "loaded) and reuse it for every style pair that follows with the same content image: consecutive "
+                        "dataset.txt lines with one content keep its feature list in memory")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
@@ -120,11 +124,16 @@ def stylise(opt, model, sampler, triple, uc, device):
                 m.kernel_flags |= ops.FLAG_BLOCK_SKIP      # kept per layer only where blocks actually die
                 m.skip_policy = "auto"
     dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
-    store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype)
     mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")
-    if not opt.unpacked_store and not opt.without_attn_injection and os.path.isfile(mask_file):
-        store.pack(compute=opt.compute)          # pre-packed K/V serve the mask-based injected attention
+    packed = not opt.unpacked_store and not opt.without_attn_injection and os.path.isfile(mask_file)
+    cache_content = packed and getattr(opt, "cache_content", False)
+    kept = getattr(sampler, "_content_kept", None)          # (content name, its feature list) of the previous triple
+    cnt_list = kept[1] if cache_content and kept is not None and kept[0] == base(cnt_path) else None
+    store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype, cnt=cnt_list)
+    if packed:
+        store.pack(compute=opt.compute, cache_content=cache_content)   # pre-packed K/V serve the mask-based injected attention
         # (every injected layer of SD-v1 has head_dim 40 or 80, which the f16 mode serves)
+    sampler._content_kept = (base(cnt_path), store.cnt) if cache_content else None
     cnt_z, char_z, back_z = store.z_enc()
     if opt.without_init_adain:
         x_T = cnt_z

@@ -23,8 +23,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define SWAP(a, b) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 
 // MODE 0: the kernel's slot (A).  MODE 1: P.V as six 16x16x32 MFMAs plus the swaps (B).
-// MODE 2: B without the swaps (the matrix side alone).  EXTRA: LDS reads, barrier and scalar work as in the kernel.
-template <int MODE, bool EXTRA>
+// MODE 2: B without the swaps (the matrix side alone).  EXTRA (bits): 1 LDS reads, 2 barrier, 4 scalar work as in the kernel.
+template <int MODE, int EXTRA>
 __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     f32x16 O0, O1, SA, SB;
     f32x4 o16[6];
@@ -45,11 +45,11 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     u32x4 fr[7];
     for (int i = 0; i < 7; ++i) fr[i] = u32x4{0u, 0u, 0u, 0u};
     unsigned sc0 = blockIdx.x, sc1 = 3;
-    auto ldsread = [&](int i) { if (EXTRA) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[i]) : "v"(laddr) : "memory"); };
-    auto salu = [&](int n) { if (EXTRA) for (int i = 0; i < n; ++i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc0) : "s"(sc1) : "scc"); };
+    auto ldsread = [&](int i) { if (EXTRA & 1) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[i]) : "v"(laddr) : "memory"); };
+    auto salu = [&](int n) { if (EXTRA & 4) for (int i = 0; i < n; ++i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sc0) : "s"(sc1) : "scc"); };
 
     auto slot = [&](f32x16& Sc, f32x16& Sn, u32x4 (&Pc)[2], u32x4 (&Pp)[2], int u) {
-        if (EXTRA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (EXTRA & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the 32 vector ops of a unit in the kernel's order, as a flat list of 32 steps
         auto vop = [&](int k) {
             const int g = k / 4, r = k % 4;          // group g of 8: exp, exp, max3, cvt(previous group)
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
         slot(SA, SB, PA, PB, 0);
         slot(SB, SA, PB, PA, 1);
         slot(SA, SB, PA, PB, 2);
-        if (EXTRA) __syncthreads();
+        if (EXTRA & 2) __syncthreads();
         slot(SB, SA, PB, PA, 3);
     }
     asm volatile("s_nop 15\n\ts_nop 15");
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
 
 static float* g_out;
 
-template <int MODE, bool EXTRA>
+template <int MODE, int EXTRA>
 void run(const char* name) {
     const int grid = 256, iters = 4000;
     for (int threads : {256, 512}) {
@@ -132,11 +132,15 @@ int main() {
     setvbuf(stdout, nullptr, _IONBF, 0);
     (void)hipMalloc(&g_out, 256 * 512 * sizeof(float));
     for (int rep = 0; rep < 2; ++rep) {
-        run<0, false>("A  P.V as 4 x 32x32x16 (the kernel's slot)");
-        run<1, false>("B  P.V as 6 x 16x16x32 + 4 permlane16_swap");
-        run<2, false>("B  without the swaps");
-        run<0, true>("A  + LDS reads, barrier, scalar work");
-        run<1, true>("B  + LDS reads, barrier, scalar work");
+        run<0, 0>("A  P.V as 4 x 32x32x16 (the kernel's slot)");
+        run<1, 0>("B  P.V as 6 x 16x16x32 + 4 permlane16_swap");
+        run<2, 0>("B  without the swaps");
+        run<0, 7>("A  + LDS reads, barrier, scalar work");
+        run<1, 7>("B  + LDS reads, barrier, scalar work");
+        run<0, 1>("A  + LDS reads only");
+        run<0, 2>("A  + barrier only");
+        run<0, 4>("A  + scalar work only");
+        run<0, 3>("A  + LDS reads, barrier");
     }
     return 0;
 }
