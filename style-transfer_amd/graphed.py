@@ -20,7 +20,11 @@ def _clone_slot(v):
     if torch.is_tensor(v):
         return v.clone()
     if isinstance(v, ops.PackedKV):
-        return ops.PackedKV(v.image.clone(), v.B, v.H, v.N, v.d, v.compute)
+        slot = ops.PackedKV(v.image.clone(), v.B, v.H, v.N, v.d, v.compute)
+        if v.partial is not None:           # a content pair with its cached content block (its q slot is tied in _capture)
+            p = v.partial
+            slot.partial = ops.ContentPartial(p.data.clone(), p.B, p.H, p.N, p.d, p.compute, p.scale, None)
+        return slot
     if isinstance(v, dict):
         return dict(v)
     return v
@@ -31,6 +35,8 @@ def _copy_into(slot, v):
         slot.copy_(v, non_blocking=True)
     elif isinstance(slot, ops.PackedKV):
         slot.image.copy_(v.image, non_blocking=True)
+        if slot.partial is not None:
+            slot.partial.data.copy_(v.partial.data, non_blocking=True)
 
 
 class GraphedUNet:
@@ -44,7 +50,9 @@ class GraphedUNet:
     def _signature(self, x, context, feats):
         cnt = tuple(getattr(m, "cnt_name", None) for m in self.unet.attention_modules()[:1])
         cfg = None if feats is None else (feats["config"].get("T"), feats["config"].get("gamma"))
-        keys = None if feats is None else tuple(sorted(k for k in feats if k != "config"))
+        # (a key is marked when its pair carries a cached content block: the evaluation then takes another entry point)
+        keys = None if feats is None else tuple(sorted(k + ("+" if getattr(v, "partial", None) is not None else "")
+                                                       for k, v in feats.items() if k != "config"))
         return (tuple(x.shape), x.dtype, None if context is None else tuple(context.shape), cnt, cfg, keys)
 
     def _capture(self, x, timesteps, context, feats):
@@ -58,6 +66,11 @@ class GraphedUNet:
                 if id(v) not in seen:
                     seen[id(v)] = _clone_slot(v)
                 self.slots[k] = seen[id(v)]
+            # a cached content block belongs to the content query it was made from: in the slots that is the
+            # query slot of the same layer (the attention call checks the address)
+            for k, slot in self.slots.items():
+                if isinstance(slot, ops.PackedKV) and slot.partial is not None and k.endswith("_k_cnt"):
+                    slot.partial.q_ptr = self.slots[k[:-len("_k_cnt")] + "_q"].data_ptr()
         self.stream = torch.cuda.Stream(device=x.device)
         self.stream.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(self.stream), torch.no_grad():

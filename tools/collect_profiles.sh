@@ -1,7 +1,8 @@
 # Collect the round's profiles on the GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the default bench command
 #   2. PMC passes over the dominant kernel (injected attention, N=4096 d=40 B=1), each its own run
-# Results land in gpurun_out/$TAG; summaries are copied into profiles/ by tools/summarise_profiles.py.
+# The raw traces stay on the box (they exceed what a call brings back); tools/summarise_profiles.py turns them
+# into the summaries under gpurun_out/${TAG}_summary, which are then copied into profiles/ by hand.
 set -e
 TAG=${1:-r1}
 OUT=/root/repo/gpurun_out/$TAG
@@ -15,4 +16,7 @@ timeout -s KILL 90 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU 
 timeout -s KILL 90 rocprofv3 --pmc FETCH_SIZE -d $OUT/p3 --output-format csv -- python3 $P 4096 40 1 3 > /dev/null 2>&1
 timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE -d $OUT/p4 --output-format csv -- python3 $P 4096 40 1 3 > /dev/null 2>&1
 timeout -s KILL 90 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/p5 --output-format csv -- python3 $P 4096 40 1 3 > /dev/null 2>&1
+python3 /root/repo/tools/summarise_profiles.py $TAG /root/repo/gpurun_out/${TAG}_summary > $OUT/../${TAG}_summary.log 2>&1
+cp $OUT/bench.err /root/repo/gpurun_out/${TAG}_summary/bench.err 2>/dev/null || true
+rm -rf $OUT
 echo collected

@@ -64,9 +64,12 @@ if base_flags & 1:
 partial = ops.content_partial(q_cnt, kv[2], d ** -0.5, H)
 cached = lambda flags=0: ops.injected_attention_cached(xq, q_cnt, kv[0], kv[1], partial, m, 0.5, 1.5, d ** -0.5, H, out=out,
                                                        flags=flags | (base_flags & ~1))
+if os.environ.get("PROF_CACHED_W"):         # force the runs per head of the cached call only (measurement)
+    os.environ["SID_TUNE_W"] = os.environ["PROF_CACHED_W"]
 cached()
 t_cached = graph_time(cached)
 t_cflash = graph_time(lambda: cached(0x20))
+os.environ.pop("SID_TUNE_W", None)
 t_partial = graph_time(lambda: ops.content_partial(q_cnt, kv[2], d ** -0.5, H))
 print("cached content block: call %.1f us | flash stage %.1f us | making the partial %.1f us" % (t_cached, t_cflash, t_partial))
 print("N=%d d=%d B=%d %s: call %.1f us (%.0f TF/s = %.1f%% of 2.5 PF) | flash stage alone %.1f us (%.1f%%)" % (

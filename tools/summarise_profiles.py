@@ -3,7 +3,7 @@ import collections, csv, glob, io, json, os, re, subprocess, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-dst = os.path.join(root, "profiles")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")      # (on the GPU box: a directory under gpurun_out/)
 os.makedirs(dst, exist_ok=True)
 
 def kstats(path, skip=None):
