@@ -223,7 +223,8 @@ long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int c
 
 /*
  * How a call would be decomposed (host arithmetic only, nothing is launched): for
- * sid_injected_attn_fwd (blocks = 3, Nq = Nk = N) or sid_plain_attn_fwd (blocks = 1) with the
+ * sid_injected_attn_fwd (blocks = 3, Nq = Nk = N), sid_injected_attn_fwd_cached (blocks = 2: the two
+ * style blocks; the content block comes from a partial) or sid_plain_attn_fwd (blocks = 1) with the
  * given shape, compute mode and flags, fills
  *   plan[0] runs per (head, query group) over the blocks' key stages   plan[1] stages of the longest run
  *   plan[2] stages per block          plan[3] partial slots per block   plan[4] waves per workgroup

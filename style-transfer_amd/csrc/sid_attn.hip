@@ -413,19 +413,33 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     g->KS = 1;
     auto cut = [&](int nb, unsigned short* bound, unsigned char* first_run, unsigned char* nseg) {
         const int Tn = nb * stages;
-        const double ctot = Tn + kSwitch * (nb - 1);
-        bound[0] = 0;
-        for (int k = 1; k <= W; ++k) {
-            const double x = ctot * k / W;
-            int s = Tn;
-            for (int b = 0; b < nb; ++b) {
-                const double lo = b * (stages + kSwitch);
-                if (x <= lo) { s = b * stages; break; }
-                if (x < lo + stages) { s = b * stages + (int)std::lround(x - lo); break; }
+        auto place = [&](double sw) {
+            const double ctot = Tn + sw * (nb - 1);
+            bound[0] = 0;
+            for (int k = 1; k <= W; ++k) {
+                const double x = ctot * k / W;
+                int s = Tn;
+                for (int b = 0; b < nb; ++b) {
+                    const double lo = b * (stages + sw);
+                    if (x <= lo) { s = b * stages; break; }
+                    if (x < lo + stages) { s = b * stages + (int)std::lround(x - lo); break; }
+                }
+                s = std::max(s, (int)bound[k - 1] + 1);       // every run holds a stage ...
+                s = std::min(s, Tn - (W - k));                  // ... and leaves one for each run after it
+                bound[k] = (unsigned short)s;
             }
-            s = std::max(s, (int)bound[k - 1] + 1);       // every run holds a stage ...
-            s = std::min(s, Tn - (W - k));                  // ... and leaves one for each run after it
-            bound[k] = (unsigned short)s;
+        };
+        place(kSwitch);
+        // where every block boundary came out as a run boundary no run changes block, so nobody pays for a
+        // change: the shares are then equal shares of the stages alone
+        auto crossing = [&]() {
+            bool c = false;
+            for (int k = 0; k < W; ++k) c |= bound[k] / stages != (bound[k + 1] - 1) / stages;
+            return c;
+        };
+        if (nb > 1 && !crossing()) {
+            place(0.0);
+            if (crossing()) place(kSwitch);
         }
         for (int b = 0; b < nb; ++b) {
             int first = -1, n = 0;
@@ -1071,7 +1085,7 @@ extern "C" long long sid_injected_attn_skip_counts_offset(int B, int H, int N, i
 extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, int compute, int flags, int plan[40]) {
     int rc = check_common(B, H, Nq, Nk, d, SID_DTYPE_F32, compute);
     if (rc != SID_OK) return rc;
-    SID_CHECK_ARG(blocks == 1 || blocks == kBlocks, "blocks must be 1 or %d (got %d)", kBlocks, blocks);
+    SID_CHECK_ARG(blocks >= 1 && blocks <= kBlocks, "blocks must be 1, 2 or %d (got %d)", kBlocks, blocks);
     SID_CHECK_ARG(blocks == 1 || Nq == Nk, "the injected attention has Nq == Nk");
     SID_CHECK_ARG(plan != nullptr, "NULL plan");
     for (int i = 0; i < 40; ++i) plan[i] = 0;

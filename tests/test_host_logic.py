@@ -121,7 +121,8 @@ def test_attention_plan_covers_every_stage_once():
     holds)."""
     shapes = [(3, 1, 8, 4096, 4096, 40), (3, 2, 8, 4096, 4096, 40), (3, 4, 8, 4096, 4096, 40), (3, 16, 8, 4096, 4096, 40),
               (3, 1, 8, 1024, 1024, 80), (3, 1, 8, 1000, 1000, 40), (3, 1, 8, 16384, 16384, 40), (3, 1, 8, 300, 300, 160),
-              (1, 1, 8, 4096, 4096, 40), (1, 2, 8, 1024, 1024, 80), (1, 1, 8, 4096, 700, 64), (3, 1, 1, 64, 64, 40)]
+              (1, 1, 8, 4096, 4096, 40), (1, 2, 8, 1024, 1024, 80), (1, 1, 8, 4096, 700, 64), (3, 1, 1, 64, 64, 40),
+              (2, 1, 8, 4096, 4096, 40), (2, 16, 8, 4096, 4096, 40), (2, 1, 8, 1024, 1024, 80), (2, 1, 8, 1000, 1000, 40)]
     for blocks, B, H, Nq, Nk, d in shapes:
         for compute in (0, 1):
             for flags in (0, 2):
@@ -155,7 +156,11 @@ def test_attention_plan_of_the_headline_shapes():
     from style_transfer_amd import lib
     import ctypes
     out = (ctypes.c_int * 40)()
-    assert lib.load().sid_attn_plan(2, 1, 8, 64, 64, 40, 0, 0, out) != 0
+    # the cached-content call runs the two style blocks: four runs of 32 stages, one workgroup per CU
+    p = _plan(2, 1, 8, 4096, 4096, 40)
+    assert (p["W"], p["KS"], p["bound"]) == (4, 2, [0, 32, 64, 96, 128])
+    assert lib.load().sid_attn_plan(4, 1, 8, 64, 64, 40, 0, 0, out) != 0
+    assert lib.load().sid_attn_plan(2, 1, 8, 64, 32, 40, 0, 0, out) != 0
     assert lib.load().sid_attn_plan(3, 1, 8, 64, 32, 40, 0, 0, out) != 0
 
 

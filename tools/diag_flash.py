@@ -1,6 +1,7 @@
 """Diagnostic build only (exp/diag.so, -DSID_DIAG): per-workgroup clock stamps of the flash kernel.
 stamps per segment: 0 start, 1 first stages landed, 2 reference pre-pass done, 3 steady loop done, 4 tails done, 5 stored.
-memrealtime ticks at 100 MHz (10 ns)."""
+memrealtime ticks at 100 MHz (10 ns).
+    python tools/diag_flash.py [N d B [plain]]      plain: the single-block call instead of the injected one"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,17 +9,20 @@ N, d, B = (int(sys.argv[i]) if len(sys.argv) > i else v for i, v in ((1, 1024), 
 dev = torch.device("cuda:0")
 diag = torch.zeros(24 * 65536, dtype=torch.int64, device=dev)
 os.environ["SID_DIAG_PTR"] = str(diag.data_ptr())
-os.environ["SID_LIB_OVERRIDE"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exp", "diag.so")
+os.environ.setdefault("SID_LIB_OVERRIDE", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exp", "diag.so"))      # (exp/ does not travel to the GPU box: copy the build to ab/ and point SID_LIB_OVERRIDE at it)
 from style_transfer_amd import ops
 H = 8
 g = torch.Generator(device=dev); g.manual_seed(0)
 rn = lambda *s: torch.randn(*s, device=dev, generator=g)
 xq = rn(B, N, H * d); f = [rn(B * H, N, d) for _ in range(7)]; m = torch.sign(rn(B, N)).contiguous()
+plain = len(sys.argv) > 4 and sys.argv[4] == "plain"
+pq, pk, pv = (rn(B, N, H * d) for _ in range(3))
+call = (lambda: ops.plain_attention(pq, pk, pv, d ** -0.5, H)) if plain else (lambda: ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H))
 for _ in range(5):
-    ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
+    call()
 torch.cuda.synchronize()
 diag.zero_()
-ops.injected_attention(xq, *f, m, 0.5, 1.5, d ** -0.5, H)
+call()
 torch.cuda.synchronize()
 raw = diag.cpu().numpy().reshape(-1, 3, 8).astype(np.float64)      # [workgroup][segment][stamp]
 raw = raw[raw[:, 0, 0] > 0]
