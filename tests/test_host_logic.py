@@ -80,6 +80,35 @@ def test_argument_checks_reject_without_a_gpu():
     assert rc == -22 and b"ch must be" in L.sid_last_error()
 
 
+def test_cached_content_block_sizes_and_argument_checks(monkeypatch):
+    """The cached content block: a partial is B*H*N rows of d halves (f32 in the f32-grade mode) plus four
+    f32 statistics per row; its call packs one query image instead of two and keeps two blocks of partials,
+    so its workspace is smaller than the packed call's; bad arguments are refused before any HIP call."""
+    from style_transfer_amd import lib
+    L = lib.load()
+    rows = 8 * 4096
+    assert L.sid_content_partial_bytes(1, 8, 4096, 40, 0) == rows * 40 * 2 + rows * 16
+    assert L.sid_content_partial_bytes(1, 8, 4096, 40, 1) == rows * 40 * 4 + rows * 16
+    assert L.sid_content_partial_bytes(1, 8, 4096, 400, 0) == 0
+    assert 0 < L.sid_injected_attn_cached_workspace_bytes(1, 8, 4096, 40, 0) < L.sid_injected_attn_packed_workspace_bytes(1, 8, 4096, 40, 0)
+    assert L.sid_content_partial_workspace_bytes(1, 8, 4096, 40, 0) > 0
+    one, al = 0x1000, 0x10000
+    rc = L.sid_injected_attn_fwd_cached(one, one, al, al, None, one, al, 1, 8, 64, 40, 0.5, 0.5, 1.5, 0.1, 0, 0, 0, al, 1 << 30, None)
+    assert rc == -22 and b"NULL" in L.sid_last_error()
+    rc = L.sid_injected_attn_fwd_cached(one, one, al, al, al + 16, one, al, 1, 8, 64, 40, 0.5, 0.5, 1.5, 0.1, 0, 0, 0, al, 1 << 30, None)
+    assert rc == -22 and b"256-byte aligned" in L.sid_last_error()
+    rc = L.sid_injected_attn_fwd_cached(one, one, al, al, al, one, al, 1, 8, 64, 40, 0.5, 0.5, 1.5, 0.1, 0, 0, 0, al, 256, None)
+    assert rc == -12 and b"workspace" in L.sid_last_error()
+    rc = L.sid_content_partial(one, al, al, 256, 1, 8, 64, 40, 0.1, 0, 0, al, 1 << 30, None)
+    assert rc == -12 and b"partial" in L.sid_last_error()
+    rc = L.sid_content_partial(one, al, al, 1 << 30, 1, 8, 64, 40, float("nan"), 0, 0, al, 1 << 30, None)
+    assert rc == -22 and b"finite" in L.sid_last_error()
+    # a forced split of the keys would need more than the one partial slot the buffer holds: refused
+    monkeypatch.setenv("SID_TUNE_W", "2")
+    assert L.sid_content_partial_workspace_bytes(1, 8, 4096, 40, 0) == 0
+    assert b"one run per head" in L.sid_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from style_transfer_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
