@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define CVT(d, x, y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
 #define SWAP(a, b) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 
-// MODE 0: the kernel's slot (A).  MODE 1: P.V as six 16x16x32 MFMAs plus the swaps (B).
+// MODE 0: the kernel's slot (A).  MODE 1: P.V as six 16x16x32 MFMAs plus the swaps (B).  MODE 3: mixed (C).
 // MODE 2: B without the swaps (the matrix side alone).  EXTRA (bits): 1 LDS reads, 2 barrier, 4 scalar work as in the kernel.
 template <int MODE, int EXTRA>
 __global__ void __launch_bounds__(512) bench(float* out, int iters) {
@@ -71,6 +71,24 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
             salu(5);
             MFMA_ACC(O0, vf[2], Pp[1]); vops(23, 28);
             MFMA_ACC(O1, vf[3], Pp[1]); vops(28, 32);
+            if (!(u & 1)) { ldsread(5); ldsread(6); }
+            salu(5);
+        } else if (MODE == 3) {
+            // mixed: output rows 0..31 as two 32x32x16 MFMAs (one per k-step), rows 32..47 as two 16x16x32 MFMAs
+            // (one per query half, on the swapped probabilities): 5 x 32 + 2 x 16 = 192 matrix-pipe cycles per
+            // unit instead of 224, the same seven MFMA issues, four swaps more on the vector port
+            MFMA_ACC(O0, vf[0], Pp[0]); vops(0, 5);
+            MFMA_ACC(O0, vf[2], Pp[1]); vops(5, 10);
+            SWAP(Pp[0][0], Pp[1][0]); SWAP(Pp[0][1], Pp[1][1]); SWAP(Pp[0][2], Pp[1][2]); SWAP(Pp[0][3], Pp[1][3]);
+            if (!(u & 1)) { ldsread(3); ldsread(4); }
+            salu(5);
+            MFMA_ZERO(Sn, kf[0], qf[0]); vops(10, 14);
+            MFMA_ACC(Sn, kf[1], qf[1]); vops(14, 19);
+            MFMA_ACC(Sn, kf[2], qf[2]); vops(19, 23);
+            if (!(u & 1)) { ldsread(0); ldsread(1); ldsread(2); }
+            salu(5);
+            MFMA16(o16[0], vf[1], Pp[0]); vops(23, 28);
+            MFMA16(o16[1], vf[3], Pp[1]); vops(28, 32);
             if (!(u & 1)) { ldsread(5); ldsread(6); }
             salu(5);
         } else {
@@ -137,6 +155,8 @@ int main() {
         run<2, 0>("B  without the swaps");
         run<0, 7>("A  + LDS reads, barrier, scalar work");
         run<1, 7>("B  + LDS reads, barrier, scalar work");
+        run<3, 0>("C  P.V rows 0..31 as 32x32x16, rows 32..47 as 16x16x32 + 4 swaps");
+        run<3, 7>("C  + LDS reads, barrier, scalar work");
         run<0, 1>("A  + LDS reads only");
         run<0, 2>("A  + barrier only");
         run<0, 4>("A  + scalar work only");
