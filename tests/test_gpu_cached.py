@@ -66,7 +66,8 @@ def test_cached_call_vs_reference_golden(case, compute):
                                                  (2, 256, 160, "bf16", torch.float32), (1, 1024, 80, "fp32", torch.float32),
                                                  (1, 576, 40, "bf16", torch.bfloat16), (1, 100, 64, "fp32", torch.float32),
                                                  (3, 333, 24, "bf16", torch.float32), (1, 4096, 40, "f16", torch.float32),
-                                                 (4, 4096, 40, "bf16", torch.float32)])
+                                                 (4, 4096, 40, "bf16", torch.float32), (1, 16384, 40, "bf16", torch.float32),
+                                                 (1, 4096, 80, "f16", torch.float32)])
 @pytest.mark.parametrize("flags", [0, ops.FLAG_THROUGHPUT])
 def test_cached_equals_three_block_call(B, N, d, compute, dtype, flags):
     """Same inputs through the packed three-block entry point and through the cached one; then the partial is
