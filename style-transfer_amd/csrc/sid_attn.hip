@@ -1138,7 +1138,8 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
         long long qs[3], ks[3];
         layout_strides(q_layout, H, Nq, d, qs);
         layout_strides(kv_layout, H, Nk, d, ks);
-        return launch_small_attn(q, k, v, out, B, H, Nq, Nk, d, logit_scale * LOG2E, qs, ks, dtype == SID_DTYPE_BF16, x3, stream);
+        return launch_small_attn(q, k, v, out, B, H, Nq, Nk, d, logit_scale * LOG2E, qs, ks, dtype == SID_DTYPE_BF16, x3, stream,
+                                 (flags & SID_FLAG_THROUGHPUT) != 0);
     }
     Geometry g;
     rc = make_geometry(B, H, Nq, Nk, d, 1, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);

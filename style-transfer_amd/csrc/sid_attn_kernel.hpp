@@ -177,7 +177,7 @@ int launch_merge(const MergeParams& mp, hipStream_t stream);
 // directly (element strides {batch, head, token}), needs no workspace.
 bool small_attn_supported(int Nk, int d);
 int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
-                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream);
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu = false);
 
 #if defined(__HIPCC__)
 

@@ -31,6 +31,7 @@ struct SmallParams {
     float c2;                                   // logit scale in the log2 domain
     int H, Nq, Nk, d, NQT, nkt, ndv;            // ndv = ceil(d / 32) output column blocks
     int out_bf16;
+    int two_tiles;                              // host only: two query tiles per workgroup where they fit
 };
 
 namespace {
@@ -268,10 +269,14 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
 //   V                 : bf16 row-major [key][vst], written after the logits are done into the space
 //                       K and Q occupied; phase 2 gathers its A fragments with 2-byte reads
 // MODE 1: f32 input (4 elements per piece), MODE 2: bf16 input (8 elements per piece).
+// QT: query tiles per workgroup.  A workgroup reads its head's whole K and V whatever it does with them,
+// and that read is what its time goes to (a CU pulls in about 11 bytes per cycle), so two query tiles per
+// workgroup halve the work of a call: every K fragment read from LDS and every V fragment gathered in
+// phase 2 feeds two MFMAs.
 // ------------------------------------------------------------------------------------------
 constexpr int kUnit = 528;
 
-template <int DKS, int MODE>
+template <int DKS, int MODE, int QT>
 __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(SmallParams P, int vst, int p_off, int st_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EPP = MODE == 1 ? 4 : 8;           // elements per 16-byte piece
@@ -285,19 +290,20 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x;
     const int hh = lane >> 5, r = lane & 31;
-    const int qt = blockIdx.x % P.NQT;
-    const int bh = blockIdx.x / P.NQT;
+    const int nqg = (P.NQT + QT - 1) / QT;           // query groups per head
+    const int qt = (blockIdx.x % nqg) * QT;          // first query tile of this workgroup
+    const int bh = blockIdx.x / nqg;
     const int b = bh / P.H, h = bh % P.H;
     const int d = P.d;
     const int pr = d / EPP;                          // valid pieces per row
     const long long qbase = b * P.qsb + h * P.qsh;
     const long long kbase = b * P.ksb + h * P.ksh;
     const bool qk_wave = wave < P.nkt, pv_wave = wave < P.ndv;
-    unsigned char* kq = smem;                        // K tiles [nkt], then the Q tile
+    unsigned char* kq = smem;                        // K tiles [nkt], then the QT query tiles
     unsigned char* qb = smem + P.nkt * TILE_BYTES;
-    float* sm_m = (float*)(smem + st_off);
-    float* sm_l = sm_m + kSmallMaxTiles * 32;
-    u32x4* sm_p = (u32x4*)(smem + p_off);
+    float* sm_m = (float*)(smem + st_off);           // [QT][key tile][32]
+    float* sm_l = sm_m + QT * kSmallMaxTiles * 32;
+    u32x4* sm_p = (u32x4*)(smem + p_off);            // [QT][key tile][2][64]
 
     // one 16-byte piece of a row -> registers (4 or 8 bf16), zero for padding columns
     auto load_piece = [&](const void* base, long long rowoff, int col, u32x4& raw) {
@@ -340,21 +346,21 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
         if (MODE == 1) { u32x2 w2 = {o[0], o[1]}; *(u32x2*)dst = w2; }
         else { u32x4 w4 = {o[0], o[1], o[2], o[3]}; *(u32x4*)dst = w4; }
     };
-    for (int f0 = 0; f0 < NPT; f0 += 4 * nthreads) {
+    for (int f0 = 0; f0 < QT * NPT; f0 += 4 * nthreads) {
         u32x4 qraw[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = min(f0 + i * nthreads + tid, NPT - 1), row = f / PRF, col = f % PRF;
+            const int f = min(f0 + i * nthreads + tid, QT * NPT - 1), row = f / PRF, col = f % PRF;     // row of the QT * 32
             load_piece(P.q, qbase + (long long)min(qt * 32 + row, P.Nq - 1) * P.qsn, col, qraw[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = f0 + i * nthreads + tid;
-            if (f < NPT) {
+            if (f < QT * NPT) {
                 const int row = f / PRF, col = f % PRF;
                 unsigned o[4];
                 to_bf16(qraw[i], col < pr, o);
-                store_piece(qb + frag_addr(row, col), o);
+                store_piece(qb + (row >> 5) * TILE_BYTES + frag_addr(row & 31, col), o);
             }
         }
     }
@@ -383,26 +389,34 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
     __syncthreads();
 
     // ---- phase 1: logits of key tile `wave`
-    float x[16];
+    float x[QT][16];
     if (qk_wave) {
-        f32x16 S;
+        f32x16 S[QT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < DKS; ++s) {
             const bf16x8 kf = as_bf16x8(*(const u32x4*)(kq + wave * TILE_BYTES + (2 * s + hh) * kUnit + r * 16));
-            const bf16x8 qf = as_bf16x8(*(const u32x4*)(qb + (2 * s + hh) * kUnit + r * 16));
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, S, 0, 0, 0);
-        }
-        float m = -SID_INF;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            x[i] = key < P.Nk ? S[i] * P.c2 : -SID_INF;
-            m = fmaxf(m, x[i]);
+            for (int t = 0; t < QT; ++t) {
+                const bf16x8 qf = as_bf16x8(*(const u32x4*)(qb + t * TILE_BYTES + (2 * s + hh) * kUnit + r * 16));
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, S[t], 0, 0, 0);
+            }
         }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (hh == 0) sm_m[wave * 32 + r] = m;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float m = -SID_INF;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                x[t][i] = key < P.Nk ? S[t][i] * P.c2 : -SID_INF;
+                m = fmaxf(m, x[t][i]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (hh == 0) sm_m[(t * kSmallMaxTiles + wave) * 32 + r] = m;
+        }
     }
     __syncthreads();          // maxima visible; nobody reads the K/Q images any more
 
@@ -417,22 +431,25 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
                 else { u32x4 w4 = {vb16[i][0], vb16[i][1], vb16[i][MODE == 1 ? 0 : 2], vb16[i][MODE == 1 ? 1 : 3]}; *(u32x4*)dst = w4; }
             }
         }
-        float M = -SID_INF;
-        for (int t = 0; t < P.nkt; ++t) M = fmaxf(M, sm_m[t * 32 + r]);
-        float pv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(x[i] - M);      // exp2(-inf) = 0 for masked keys
-        bf16x8 p0, p1;
-        float l = 0.f;
+        for (int t = 0; t < QT; ++t) {
+            float M = -SID_INF;
+            for (int kt = 0; kt < P.nkt; ++kt) M = fmaxf(M, sm_m[(t * kSmallMaxTiles + kt) * 32 + r]);
+            float pv[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            p0[j] = (__bf16)pv[j]; p1[j] = (__bf16)pv[8 + j];
-            l += (float)p0[j] + (float)p1[j];      // the denominator sums the rounded numerators
+            for (int i = 0; i < 16; ++i) pv[i] = __builtin_amdgcn_exp2f(x[t][i] - M);      // exp2(-inf) = 0 for masked keys
+            bf16x8 p0, p1;
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p0[j] = (__bf16)pv[j]; p1[j] = (__bf16)pv[8 + j];
+                l += (float)p0[j] + (float)p1[j];      // the denominator sums the rounded numerators
+            }
+            l += __shfl_xor(l, 32);
+            if (hh == 0) sm_l[(t * kSmallMaxTiles + wave) * 32 + r] = l;
+            sm_p[((t * kSmallMaxTiles + wave) * 2 + 0) * 64 + lane] = bits(p0);
+            sm_p[((t * kSmallMaxTiles + wave) * 2 + 1) * 64 + lane] = bits(p1);
         }
-        l += __shfl_xor(l, 32);
-        if (hh == 0) sm_l[wave * 32 + r] = l;
-        sm_p[(wave * 2 + 0) * 64 + lane] = bits(p0);
-        sm_p[(wave * 2 + 1) * 64 + lane] = bits(p1);
     }
     __syncthreads();
 
@@ -441,69 +458,108 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
     const int dv = 32 * wave + r;
     const bool dv_ok = dv < d;
     const unsigned char* vcol = smem + min(dv, d - 1) * 2;
-    f32x16 O;
+    f32x16 O[QT];
+    float l[QT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) O[i] = 0.f;
-    float l = 0.f;
-    for (int t = 0; t < P.nkt; ++t) {
-        l += sm_l[t * 32 + r];
+    for (int t = 0; t < QT; ++t) {
+        l[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[t][i] = 0.f;
+    }
+    for (int kt = 0; kt < P.nkt; ++kt) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) l[t] += sm_l[(t * kSmallMaxTiles + kt) * 32 + r];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             unsigned w[4];
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {
                 const int j = 2 * jp;
-                const int key = 32 * t + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);     // j and j+1 are adjacent keys
+                const int key = 32 * kt + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3);     // j and j+1 are adjacent keys
                 const unsigned lo = *(const unsigned short*)(vcol + key * vst);
                 const unsigned hi = *(const unsigned short*)(vcol + (key + 1) * vst);
                 w[jp] = dv_ok ? (lo | (hi << 16)) : 0u;
             }
             u32x4 vfrag = {w[0], w[1], w[2], w[3]};
-            O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vfrag), as_bf16x8(sm_p[(t * 2 + s2) * 64 + lane]), O, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vfrag),
+                                                               as_bf16x8(sm_p[((t * kSmallMaxTiles + kt) * 2 + s2) * 64 + lane]), O[t], 0, 0, 0);
         }
     }
-    const int q = qt * 32 + r;
-    if (q >= P.Nq) return;
-    const float inv = 1.0f / l;
-    const size_t obase = ((size_t)b * P.Nq + q) * P.H * d + (size_t)h * d;
     const bool ovec = !P.out_bf16 && (d & 3) == 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int dv0 = 32 * wave + 8 * g + 4 * hh;
-        if (ovec) {
-            if (dv0 < d) {
-                f32x4 o = {O[4 * g] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
-                *(f32x4*)((float*)P.out + obase + dv0) = o;
-            }
-        } else {
+    for (int t = 0; t < QT; ++t) {
+        const int q = (qt + t) * 32 + r;
+        if (q >= P.Nq) continue;
+        const float inv = 1.0f / l[t];
+        const size_t obase = ((size_t)b * P.Nq + q) * P.H * d + (size_t)h * d;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (dv0 + e < d) {
-                    const float val = O[4 * g + e] * inv;
-                    if (P.out_bf16) ((__bf16*)P.out)[obase + dv0 + e] = (__bf16)val;
-                    else ((float*)P.out)[obase + dv0 + e] = val;
+        for (int g = 0; g < 4; ++g) {
+            const int dv0 = 32 * wave + 8 * g + 4 * hh;
+            if (ovec) {
+                if (dv0 < d) {
+                    f32x4 o = {O[t][4 * g] * inv, O[t][4 * g + 1] * inv, O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv};
+                    *(f32x4*)((float*)P.out + obase + dv0) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (dv0 + e < d) {
+                        const float val = O[t][4 * g + e] * inv;
+                        if (P.out_bf16) ((__bf16*)P.out)[obase + dv0 + e] = (__bf16)val;
+                        else ((float*)P.out)[obase + dv0 + e] = val;
+                    }
                 }
             }
         }
     }
 }
 
-template <int DKS, int MODE>
-int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream) {
+// LDS of the staged kernel with QT query tiles per workgroup: [K tiles + QT query tiles | V rows] (shared),
+// the probabilities and the row statistics of every query tile
+struct SmallLds { int vst; size_t p_off, st_off, bytes; };
+template <int DKS>
+SmallLds small_lds_layout(const SmallParams& p, int QT) {
+    SmallLds L;
     // V row stride in bytes: 16-byte multiple whose bank offset between the two lane halves
     // (rows 4 apart) clears the 16 banks one half covers
-    int vst = (2 * p.d + 15) / 16 * 16;
-    while (vst % 64 < 16 || vst % 64 > 48) vst += 16;
-    const size_t images = std::max((size_t)(p.nkt + 1) * 2 * DKS * kUnit, (size_t)p.nkt * 32 * vst);
-    const size_t p_off = (images + 255) / 256 * 256;
-    const size_t st_off = p_off + (size_t)kSmallMaxTiles * 2 * 1024;
-    const size_t lds = st_off + 2 * kSmallMaxTiles * 32 * sizeof(float);
-    constexpr auto kern = small_attn_lds_kernel<DKS, MODE>;
+    L.vst = (2 * p.d + 15) / 16 * 16;
+    while (L.vst % 64 < 16 || L.vst % 64 > 48) L.vst += 16;
+    const size_t images = std::max((size_t)(p.nkt + QT) * 2 * DKS * kUnit, (size_t)p.nkt * 32 * L.vst);
+    L.p_off = (images + 255) / 256 * 256;
+    L.st_off = L.p_off + (size_t)QT * kSmallMaxTiles * 2 * 1024;
+    L.bytes = L.st_off + (size_t)QT * 2 * kSmallMaxTiles * 32 * sizeof(float);
+    return L;
+}
+
+template <int DKS, int MODE, int QT>
+int launch_small_lds_qt(const SmallParams& p, int BH, int waves, const SmallLds& L, hipStream_t stream) {
+    constexpr auto kern = small_attn_lds_kernel<DKS, MODE, QT>;
     const int rc = sid::allow_dynamic_lds<kern>(160 * 1024);
     if (rc != SID_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(BH * p.NQT)), dim3(waves * 64), lds, stream, p, vst, (int)p_off, (int)st_off);
+    const int nqg = (p.NQT + QT - 1) / QT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(BH * nqg)), dim3(waves * 64), L.bytes, stream, p, L.vst, (int)L.p_off, (int)L.st_off);
     SID_CHECK_HIP(hipGetLastError());
     return SID_OK;
+}
+
+template <int DKS, int MODE>
+int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream) {
+    // Two query tiles per workgroup halve the work of a call and add a quarter to the time of one workgroup
+    // (measured, one -> two tiles: (256,256,160) 11.1 -> 13.9 us at one image, 21.4 -> 18.6 us at four;
+    // (4096,77,40) 9.3 -> 8.7 us at one image, 27.7 -> 23.4 us at four; (1024,77,80) 6.2 -> 7.5 us): taken
+    // when the GPU is full anyway, i.e. the call shares it with other streams, launches two workgroups per
+    // CU by itself, or one per CU with a K/V long enough to be the workgroup's main cost.
+    // SID_TUNE_SMALL_QT = 1 / 2 forces the choice (measurement and tests only).
+    const char* e = getenv("SID_TUNE_SMALL_QT");
+    const SmallLds two = small_lds_layout<DKS>(p, 2);
+    const long long wgs = (long long)BH * p.NQT;
+    const bool full = p.two_tiles || wgs >= 512 || (wgs >= 256 && p.Nk >= 128);
+    const bool want = (e && e[0] == '2') || (!(e && e[0] == '1') && full);
+    if (want && p.NQT >= 2 && two.bytes <= 160 * 1024)
+        return launch_small_lds_qt<DKS, MODE, 2>(p, BH, waves, two, stream);
+    return launch_small_lds_qt<DKS, MODE, 1>(p, BH, waves, small_lds_layout<DKS>(p, 1), stream);
 }
 
 template <int DKS, int NKT, bool X3>
@@ -547,8 +603,9 @@ int launch_small_dks(const SmallParams& p, int BH, int waves, bool x3, bool bf16
 bool small_attn_supported(int Nk, int d) { return Nk <= 32 * kSmallMaxTiles && (d + 31) / 32 <= kSmallMaxTiles && d <= 160; }
 
 int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
-                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream) {
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu) {
     SmallParams p = {};
+    p.two_tiles = shared_gpu;
     p.q = q; p.k = k; p.v = v; p.out = out;
     p.qsb = qs[0]; p.qsh = qs[1]; p.qsn = qs[2]; p.ksb = ks[0]; p.ksh = ks[1]; p.ksn = ks[2];
     p.c2 = c2; p.H = H; p.Nq = Nq; p.Nk = Nk; p.d = d;

@@ -203,6 +203,30 @@ def test_short_sequence_kernel(B, Nq, Nk, d, layout, dtype, compute, staging, mo
         assert rel_err(out[b], ref) < tol, b
 
 
+@pytest.mark.parametrize("B,Nq,Nk,d,dtype", [(1, 256, 256, 160, torch.float32), (2, 64, 64, 160, torch.float32),
+                                             (1, 4096, 77, 40, torch.float32), (1, 1000, 77, 80, torch.bfloat16),
+                                             (3, 96, 200, 24, torch.float32), (1, 33, 256, 160, torch.bfloat16)])
+def test_short_sequence_kernel_two_query_tiles_per_workgroup(B, Nq, Nk, d, dtype, monkeypatch):
+    """The staged short-sequence kernel with one and with two query tiles per workgroup (what a call that
+    shares the GPU takes): the arithmetic of a query tile is the same, so the results are bit-identical;
+    odd tile counts and ragged last tiles included; the throughput flag selects the two-tile form."""
+    H = 8
+    mk = lambda seed, n: torch.from_numpy(synth.normal(seed, (B, n, H * d))).to(dtype).to("cuda:0")
+    q, k, v = mk(4460, Nq), mk(4461, Nk), mk(4462, Nk)
+    monkeypatch.setenv("SID_TUNE_SMALL_QT", "1")
+    one = ops.plain_attention(q, k, v, d ** -0.5, H).clone()
+    monkeypatch.setenv("SID_TUNE_SMALL_QT", "2")
+    two = ops.plain_attention(q, k, v, d ** -0.5, H).clone()
+    monkeypatch.delenv("SID_TUNE_SMALL_QT")
+    shared = ops.plain_attention(q, k, v, d ** -0.5, H, flags=ops.FLAG_THROUGHPUT)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(one, two) and torch.equal(one, shared)
+    sp = lambda t: np.stack([orc.split_heads(x, H) for x in t.float().cpu().numpy()])
+    ref = orc.plain_attention(sp(q)[B - 1], sp(k)[B - 1], sp(v)[B - 1], d ** -0.5, dtype=np.float64)
+    assert rel_err(two[B - 1].float().cpu().numpy(), ref) < (TOL["bf16"] if dtype == torch.float32 else max(TOL["bf16"], 2 ** -7))
+
+
 def test_repeated_calls_and_stage_by_stage_calls_agree():
     """The same call repeated, and the same call issued stage by stage (pack, flash, merge) on one
     workspace, give bit-identical rows."""
