@@ -280,6 +280,16 @@ int sid_hf_filter_radius(const void* h_cnt, const void* skip, const void* h, voi
                          int B, int C, int H, int W, int radius, int dtype, void* stream);
 
 /*
+ * The patched ResBlock sum with HF(h_cnt) made earlier:  out = (skip + h) + hf  over n elements.
+ * Replaces high_frequency_final.py:82-88 for callers that keep the filtered content residual of a
+ * (timestep, block) -- sid_hf_filter with skip = h = NULL -- because it depends on the content image and
+ * the ratio only (high_frequency_final.py:70-81): one content image stylised with several style pairs
+ * filters once.  Same additions in the same order as the fused form of sid_hf_filter: same bits.
+ *   skip, h, hf, out: n elements of `dtype`, aligned to four elements.
+ */
+int sid_residual_sum(const void* skip, const void* h, const void* hf, void* out, long long n, int dtype, void* stream);
+
+/*
  * Masked AdaIN initial latent.
  * Replaces run_ori.py:77-82 (adain: per-channel mean / unbiased std over (batch, H, W)) and
  * run_ori.py:228-232 (bilinear resize of the raw [0,1] mask to the latent size, no threshold;

@@ -531,3 +531,63 @@ extern "C" int sid_hf_filter(const void* h_cnt, const void* skip, const void* h,
     const int radius = (int)((double)std::min(H, W) * (double)ratio);
     return hf_common(h_cnt, skip, h, out, B, C, H, W, radius, dtype, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// out = (skip + h) + hf, the patched ResBlock sum with HF(h_cnt) computed earlier: the same additions
+// in the same order as the epilogue of the fused filter, so both routes give the same bits.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <bool BF16>
+__global__ void __launch_bounds__(256) residual_sum_kernel(const void* __restrict__ skip, const void* __restrict__ hres,
+                                                           const void* __restrict__ hf, void* __restrict__ out,
+                                                           long long n4, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float a[4], b[4], c[4];
+        ld4<BF16>(skip, 4 * (size_t)i, a); ld4<BF16>(hres, 4 * (size_t)i, b); ld4<BF16>(hf, 4 * (size_t)i, c);
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (BF16) r[j] = (float)(__bf16)(a[j] + b[j]) + c[j];       // (skip + h) rounds to bf16, then + HF rounds again
+            else r[j] = __fadd_rn(__fadd_rn(a[j], b[j]), c[j]);
+        }
+        if (BF16) {
+            __bf16* op = (__bf16*)out + 4 * i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) op[j] = (__bf16)r[j];
+        } else {
+            *(float4*)((float*)out + 4 * i) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    // the last n % 4 elements, one thread each
+    const long long t = 4 * n4 + i;
+    if (i < n - 4 * n4) {
+        if (BF16) {
+            const __bf16 *sa = (const __bf16*)skip, *sb = (const __bf16*)hres, *sc = (const __bf16*)hf;
+            ((__bf16*)out)[t] = (__bf16)((float)(__bf16)((float)sa[t] + (float)sb[t]) + (float)sc[t]);
+        } else {
+            const float *sa = (const float*)skip, *sb = (const float*)hres, *sc = (const float*)hf;
+            ((float*)out)[t] = __fadd_rn(__fadd_rn(sa[t], sb[t]), sc[t]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sid_residual_sum(const void* skip, const void* h, const void* hf, void* out, long long n, int dtype,
+                                void* stream) {
+    SID_CHECK_ARG(skip && h && hf && out, "NULL tensor pointer");
+    SID_CHECK_ARG(n >= 1, "n must be >= 1 (got %lld)", n);
+    SID_CHECK_ARG(dtype == SID_DTYPE_F32 || dtype == SID_DTYPE_BF16, "unknown dtype %d", dtype);
+    const uintptr_t al = (uintptr_t)skip | (uintptr_t)h | (uintptr_t)hf | (uintptr_t)out;
+    SID_CHECK_ARG((al & (dtype == SID_DTYPE_F32 ? 15 : 7)) == 0, "tensors must be aligned to four elements");
+    const long long n4 = n / 4;
+    const unsigned blocks = (unsigned)((std::max(n4, n - 4 * n4) + 255) / 256);
+    if (dtype == SID_DTYPE_BF16)
+        hipLaunchKernelGGL(residual_sum_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, skip, h, hf, out, n4, n);
+    else
+        hipLaunchKernelGGL(residual_sum_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, skip, h, hf, out, n4, n);
+    SID_CHECK_HIP(hipGetLastError());
+    return SID_OK;
+}

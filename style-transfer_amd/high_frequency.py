@@ -43,11 +43,22 @@ def resblock_hf_sum(out_skip, out_h, h_cnt, ratio=0.5):
     return ops.hf_filter(h_cnt.contiguous(), ratio, skip=out_skip.contiguous(), h=out_h.contiguous())
 
 
-def patch_decoder_resblocks_h_and_cnt_hf(unet, schedule, residuals_all, ratio=0.5):
+def resblock_cached_hf_sum(out_skip, out_h, h_cnt, ratio, cache, key):
+    """resblock_hf_sum with HF(h_cnt) kept in `cache[key]`: filtered at the first use, added by
+    sid_residual_sum from then on (the same bits: the fused kernel adds in the same order)."""
+    hf = cache.get(key)
+    if hf is None or hf.dtype != out_skip.dtype or hf.device != out_skip.device:
+        hf = cache[key] = high_freq_filter(h_cnt.to(device=out_skip.device, dtype=out_skip.dtype), ratio)
+    return ops.residual_sum(out_skip.contiguous(), out_h.contiguous(), hf)
+
+
+def patch_decoder_resblocks_h_and_cnt_hf(unet, schedule, residuals_all, ratio=0.5, hf_cache=None):
     """Rebind `_forward` of the last ResBlock of output blocks 6..11 so that, on scheduled
     timesteps with a stored content residual, it returns out_skip + out_h + HF(h_cnt)
     (high_frequency_final.py:46-92).  The block must expose `out_skip` / `out_h` after its
-    original `_forward`, and the sampler sets `ri_timestep` on it."""
+    original `_forward`, and the sampler sets `ri_timestep` on it.
+    hf_cache: a dict the caller keeps per (content image, ratio).  HF(h_cnt) depends on nothing else, so
+    with it every (timestep, block) is filtered once and reused for every style pair of that content."""
     for block_id in range(6, 12):
         if block_id >= len(unet.output_blocks):
             break
@@ -64,7 +75,9 @@ def patch_decoder_resblocks_h_and_cnt_hf(unet, schedule, residuals_all, ratio=0.
                 t = getattr(self, "ri_timestep", None)
                 if t in schedule and t in residuals_all:
                     h_cnt = residuals_all[t].get("output_block_%d_cnt_h" % self.block_id, None)
-                    if h_cnt is not None:
+                    if h_cnt is not None and hf_cache is not None and _kernel_ok(h_cnt.to(self.out_skip.device)):
+                        out = resblock_cached_hf_sum(self.out_skip, self.out_h, h_cnt, ratio, hf_cache, (t, self.block_id))
+                    elif h_cnt is not None:
                         out = resblock_hf_sum(self.out_skip, self.out_h, h_cnt, ratio)
                 return out
 

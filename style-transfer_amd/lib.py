@@ -41,6 +41,7 @@ SIGNATURES = {
     "sid_mask_downsample": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "sid_hf_filter": (_i, [_vp] * 4 + [_i] * 4 + [_f, _i, _vp]),
     "sid_hf_filter_radius": (_i, [_vp] * 4 + [_i] * 4 + [_i, _i, _vp]),
+    "sid_residual_sum": (_i, [_vp] * 4 + [_c.c_longlong, _i, _vp]),
     "sid_masked_adain": (_i, [_vp] * 4 + [_i, _i, _vp] + [_i] * 5 + [_vp]),
 }
 

@@ -361,6 +361,22 @@ def hf_filter(h_cnt, ratio=0.5, skip=None, h=None, out=None):
     return out
 
 
+def residual_sum(skip, h, hf, out=None):
+    """(skip + h) + hf: the patched ResBlock sum with HF(h_cnt) filtered earlier (hf_filter without skip / h);
+    the same bits as the fused hf_filter(h_cnt, ratio, skip, h)."""
+    L = _lib.load()
+    dev = _need_cuda(skip, h, hf)
+    for t in (h, hf):
+        if t.shape != skip.shape or t.dtype != skip.dtype:
+            raise ValueError("skip, h and hf must share shape and dtype")
+    if out is None:
+        out = torch.empty_like(skip)
+    with torch.cuda.device(dev):
+        _lib.check(L.sid_residual_sum(skip.data_ptr(), h.data_ptr(), hf.data_ptr(), out.data_ptr(), skip.numel(),
+                                      _dtype_code(skip), _stream(dev)))
+    return out
+
+
 def masked_adain(cnt, sty_char, sty_back=None, mask=None, out=None):
     """m * adain(cnt, sty_char) + (1 - m) * adain(cnt, sty_back) with m the raw (Hin, Win) float32 mask
     resized bilinearly to the latent; with sty_back and mask None: adain(cnt, sty_char).  (B,C,H,W)."""

@@ -147,7 +147,12 @@ def stylise(opt, model, sampler, triple, uc, device):
         from .sampler import last_resblocks
         residuals = fs.load_residuals_file(res_path, device)
         schedule = set(int(t) for t in make_content_injection_schedule(sampler.ddim_timesteps, alpha=0.4))
-        patch_decoder_resblocks_h_and_cnt_hf(model, schedule, residuals, ratio=opt.ratio)
+        hf_cache = None
+        if getattr(opt, "cache_content", False):            # HF(h_cnt) too depends on the content image (and the ratio) alone
+            kept = getattr(sampler, "_hf_kept", None)
+            hf_cache = kept[1] if kept is not None and kept[0] == (base(cnt_path), opt.ratio) else {}
+            sampler._hf_kept = ((base(cnt_path), opt.ratio), hf_cache)
+        patch_decoder_resblocks_h_and_cnt_hf(model, schedule, residuals, ratio=opt.ratio, hf_cache=hf_cache)
         for _, m in last_resblocks(model):
             m.ri_timestep = None                                       # no stale timestep from the previous image
 

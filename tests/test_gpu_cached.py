@@ -190,3 +190,37 @@ def test_partials_made_on_side_streams_equal_those_made_in_line():
     for (q, kv, scale), p in zip(jobs, many):
         one = ops.content_partial(q, kv, scale, H)
         assert torch.equal(one.data, p.data) and p.q_ptr == q.data_ptr()
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 320, 64, 64), torch.float32), ((2, 8, 32, 32), torch.float32),
+                                         ((1, 5, 8, 16), torch.float32), ((1, 640, 32, 32), torch.bfloat16),
+                                         ((1, 4, 128, 128), torch.bfloat16)])
+@pytest.mark.parametrize("ratio", [0.5, 0.25])
+def test_cached_hf_sum_equals_the_fused_filter_bit_for_bit(shape, dtype, ratio):
+    """HF(h_cnt) filtered once (bare sid_hf_filter) and added by sid_residual_sum against the fused
+    skip + h + HF(h_cnt): the same additions in the same order, so the same bits; and against the oracle."""
+    h_cnt, skip, h = (torch.from_numpy(synth.normal(4800 + i, shape)).to(DEV).to(dtype) for i in range(3))
+    fused = ops.hf_filter(h_cnt, ratio, skip=skip, h=h)
+    hf = ops.hf_filter(h_cnt, ratio)
+    got = ops.residual_sum(skip, h, hf)
+    torch.cuda.synchronize()
+    assert torch.equal(got, fused)
+    if dtype == torch.float32:
+        want = orc.resblock_hf_merge(skip.cpu().numpy(), h.cpu().numpy(), h_cnt.cpu().numpy(), ratio)
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-4 * np.abs(want).max()
+    from style_transfer_amd.high_frequency import resblock_cached_hf_sum
+    cache = {}
+    a = resblock_cached_hf_sum(skip, h, h_cnt, ratio, cache, (1, 6))
+    b = resblock_cached_hf_sum(skip, h, torch.zeros_like(h_cnt), ratio, cache, (1, 6))     # the second use reads the cache
+    assert torch.equal(a, fused) and torch.equal(b, fused) and len(cache) == 1
+
+
+def test_residual_sum_tail_and_argument_checks():
+    L = lib.load()
+    a, b, c = (torch.from_numpy(synth.normal(4900 + i, (1003,))).to(DEV) for i in range(3))      # 1003 = 4 * 250 + 3
+    got = ops.residual_sum(a, b, c)
+    assert torch.equal(got, (a + b) + c)
+    rc = L.sid_residual_sum(a.data_ptr(), b.data_ptr(), None, got.data_ptr(), 1003, 0, None)
+    assert rc == -22 and b"NULL" in L.sid_last_error()
+    rc = L.sid_residual_sum(a.data_ptr() + 4, b.data_ptr(), c.data_ptr(), got.data_ptr(), 8, 0, None)
+    assert rc == -22 and b"aligned" in L.sid_last_error()
