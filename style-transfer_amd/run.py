@@ -210,7 +210,11 @@ def main(argv=None):
     uc = (torch.load(opt.uc, map_location=device, weights_only=True) if opt.uc
           else torch.zeros(1, 77, 768, device=device))
     triples = list_triples(opt.data_root)
-    mine = sharding.shard_indices(len(triples), rank, world)
+    # with --cache_content all triples of a content image go to one rank (what is kept per content image is
+    # kept per rank); otherwise round-robin
+    lists = (sharding.shard_by_content([base(t[0]) for t in triples], world) if opt.cache_content
+             else [sharding.shard_indices(len(triples), r, world) for r in range(world)])
+    mine = lists[rank]
     begin = time.time()
     latents = []
     with torch.no_grad():
@@ -221,12 +225,12 @@ def main(argv=None):
             torch.save(z.cpu(), os.path.join(opt.output_path, name))  # run_ori.py:245 names the PNG the same way
     shape = (opt.C, opt.H // opt.f, opt.W // opt.f)
     local_stack = torch.stack(latents) if latents else torch.zeros((0,) + shape, device=device)
-    local_stack, _ = sharding.pad_to_common(local_stack, len(triples), world)
+    local_stack, _ = sharding.pad_to_common(local_stack, len(triples), world, per=max(len(l) for l in lists))
     if dist is not None and backend != "nccl":
         local_stack = local_stack.cpu()
     gathered = sharding.gather_latents(local_stack, dist, dst=0)
     if rank == 0:
-        allz = sharding.reassemble(gathered, len(triples))
+        allz = sharding.reassemble_lists(gathered, lists)
         torch.save(allz.cpu(), os.path.join(opt.output_path, "latents_all.pt"))
         print("Total end: %.3f s for %d triples on %d GPU(s)" % (time.time() - begin, len(triples), world))
     if dist is not None:

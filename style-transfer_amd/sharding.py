@@ -11,6 +11,33 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def shard_by_content(content_keys, world):
+    """Partition for runs that reuse what depends on the content image alone (its feature list, cached
+    content blocks, filtered residuals): all items with one content key go to ONE rank, in dataset order.
+    Groups are placed largest first on the rank with the fewest items so far (ties: the lower rank), so the
+    assignment is the same on every rank without any exchange.  Returns one index list per rank, the items
+    of a content key next to each other (a rank that walks its list meets every content image once)."""
+    groups = {}
+    for i, key in enumerate(content_keys):
+        groups.setdefault(key, []).append(i)
+    order = sorted(groups.values(), key=lambda g: (-len(g), g[0]))
+    lists = [[] for _ in range(world)]
+    for g in order:
+        r = min(range(world), key=lambda r: (len(lists[r]), r))
+        lists[r].extend(g)
+    return lists
+
+
+def reassemble_lists(stacked, lists):
+    """Undo an arbitrary static partition on `dst`: row j of rank r's block is item lists[r][j]."""
+    n = sum(len(l) for l in lists)
+    out = torch.empty((n,) + tuple(stacked.shape[2:]), dtype=stacked.dtype, device=stacked.device)
+    for r, l in enumerate(lists):
+        if l:
+            out[torch.as_tensor(l, device=stacked.device)] = stacked[r, :len(l)]
+    return out
+
+
 def gather_latents(local, dist=None, dst=0):
     """local: (n_local, ...) latents of this rank, same n_local on every rank (pad with
     `pad_to_common` first).  Returns on `dst` the (world, n_local, ...) stack, elsewhere None.  One
@@ -23,10 +50,11 @@ def gather_latents(local, dist=None, dst=0):
     return torch.stack(bufs) if rank == dst else None
 
 
-def pad_to_common(local, n_items, world):
-    """Ranks hold ceil or floor of n_items / world items; pad with zeros to the ceil so that the
-    gather has one shape.  Returns (padded, n_valid)."""
-    per = -(-n_items // world)
+def pad_to_common(local, n_items, world, per=None):
+    """Ranks hold ceil or floor of n_items / world items; pad with zeros to the ceil (or to `per`, the
+    longest list of a partition that is not round-robin) so that the gather has one shape.
+    Returns (padded, n_valid)."""
+    per = -(-n_items // world) if per is None else per
     n = local.shape[0]
     if n < per:
         pad = torch.zeros((per - n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

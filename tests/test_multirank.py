@@ -52,6 +52,40 @@ def test_shard_indices_cover_every_item_once():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_by_content_keeps_a_content_image_on_one_rank():
+    """The partition of runs that keep per-content state: every item once, all items of a content key on one
+    rank, the same answer whoever computes it, loads balanced to within the largest group."""
+    import random
+    rnd = random.Random(7)
+    for trial in range(30):
+        n_keys, world = rnd.randint(1, 12), rnd.choice((1, 2, 3, 8))
+        keys = [("c%d" % rnd.randrange(n_keys)) for _ in range(rnd.randint(0, 40))]
+        lists = sharding.shard_by_content(keys, world)
+        assert len(lists) == world and sorted(i for l in lists for i in l) == list(range(len(keys)))
+        owner = {}
+        for r, l in enumerate(lists):
+            for i in l:
+                assert owner.setdefault(keys[i], r) == r
+            runs = [keys[i] for j, i in enumerate(l) if j == 0 or keys[i] != keys[l[j - 1]]]
+            assert len(runs) == len(set(runs))                 # the items of a content key sit next to each other
+        assert lists == sharding.shard_by_content(list(keys), world)
+        biggest = max([keys.count(k) for k in set(keys)] or [0])
+        assert max(len(l) for l in lists) - min(len(l) for l in lists) <= max(biggest, 1)
+    # one content per line (the reference's dataset.txt): the same loads as round-robin
+    lists = sharding.shard_by_content(["c%d" % i for i in range(10)], 4)
+    assert sorted(len(l) for l in lists) == [2, 2, 3, 3]
+    # gather of a ragged, non-round-robin partition comes back in dataset order
+    keys = ["a", "b", "a", "a", "c", "b"]
+    lists = sharding.shard_by_content(keys, 2)
+    per = max(len(l) for l in lists)
+    blocks = []
+    for l in lists:
+        x = torch.stack([torch.full((2, 3), float(i)) for i in l]) if l else torch.zeros((0, 2, 3))
+        blocks.append(sharding.pad_to_common(x, len(keys), 2, per=per)[0])
+    full = sharding.reassemble_lists(torch.stack(blocks), lists)
+    assert [float(full[i, 0, 0]) for i in range(len(keys))] == [0., 1., 2., 3., 4., 5.]
+
+
 def test_single_process_gather_is_identity():
     x = torch.arange(24.0).reshape(3, 2, 4)
     assert torch.equal(sharding.reassemble(sharding.gather_latents(x), 3), x)
