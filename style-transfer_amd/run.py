@@ -63,8 +63,8 @@ def build_parser():
                         "every layer keeps the flag for an image only if its first call dropped something")
     p.add_argument('--cache_content', action='store_true',
                    help="compute the content block of the injected attention once per content image (when its features are "
-                        "loaded) and reuse it for every style pair that follows with the same content image: consecutive "
-                        "dataset.txt lines with one content keep its feature list in memory")
+                        "loaded) and reuse it, its feature list and its filtered residuals for every style pair with the "
+                        "same content image: the dataset.txt lines of one content are processed next to each other, on one rank")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
     return p
 
