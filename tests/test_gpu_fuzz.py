@@ -1,7 +1,8 @@
 """Seeded random shapes through both attention entry points against the float64 oracle: token counts
 that are not multiples of the tile or stage sizes, every head_dim class (including the ones served by a
 larger kernel instance and the ones whose rows are not 16-byte aligned), several heads and batch sizes,
-soft mask values, random gamma / T, all arithmetic modes, packed and unpacked key/value pairs."""
+soft mask values, random gamma / T, all arithmetic modes, packed and unpacked key/value pairs, the content
+block computed in the call and taken from a partial."""
 import numpy as np
 import pytest
 import torch
@@ -58,6 +59,14 @@ def test_random_injected_shapes(c):
         packed = ops.injected_attention_packed(g["xq"], g["q_cnt"], kv[0], kv[1], kv[2], mg, c["gamma"], c["T"], scale, H,
                                                flags=ops.FLAG_THROUGHPUT)
         assert torch.equal(packed, out), mode
+        # the content block from a partial made once: the same rows against the oracle, both decompositions
+        partial = ops.content_partial(g["q_cnt"], kv[2], scale, H)
+        for flags in (0, ops.FLAG_THROUGHPUT):
+            cached = ops.injected_attention_cached(g["xq"], g["q_cnt"], kv[0], kv[1], partial, mg, c["gamma"], c["T"], scale, H,
+                                                   flags=flags).cpu().numpy()
+            assert np.isfinite(cached).all(), (mode, flags)
+            for b in range(B):
+                assert rel_err(cached[b][rows], refs[b]) < TOL[mode], (mode, flags, b, "cached")
 
 
 @pytest.mark.parametrize("c", [_case(100 + i) for i in range(24)], ids=lambda c: "%(i)d-N%(N)d-d%(d)d-H%(H)d-B%(B)d" % c)
