@@ -20,7 +20,7 @@ its own N ranks (one process per GPU) before anything touches a GPU; under torch
 uses the ranks it is given.  Every rank stylises its own images (the path shards over images, no
 data-path collective) and rank 0 gathers the output latents once at the end over RCCL.
 
-Images are independent, so each GPU keeps `--in-flight` (default 3) of them going at once, one HIP
+Images are independent, so each GPU keeps `--in-flight` (default 4) of them going at once, one HIP
 stream and one workload each, and the ~2300 kernel launches of an image are captured once as a HIP
 graph and replayed.  `--in-flight 1 --no-graph` is the plain one-image-at-a-time launch sequence.
 """
@@ -64,7 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (host UNet around the path)")
     ap.add_argument("--no-block-skip", action="store_true", help="skip the SID_FLAG_BLOCK_SKIP on/off record")
     ap.add_argument("--no-content-cache", action="store_true", help="skip the cached-content-block record")
-    ap.add_argument("--in-flight", type=int, default=3, help="images processed concurrently per GPU (one stream each)")
+    ap.add_argument("--in-flight", type=int, default=4, help="images processed concurrently per GPU (one stream each)")
+    ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process and its ranks (0: leave the environment alone)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo only to rehearse on one GPU")
     ap.add_argument("--rank-probe", action="store_true", help=argparse.SUPPRESS)   # launcher test: print the rank environment and exit
@@ -94,6 +95,11 @@ def launch_ranks(n, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    # One hardware queue per image lane besides the default stream's: the runtime's default of four makes the
+    # fourth lane share a queue (43 instead of 54 imgs/s).  Read by the HIP runtime when it starts, which in
+    # this process (and in the ranks it starts) has not happened yet.
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -296,7 +302,7 @@ def block_skip_record(dev, compute):
             torch.cuda.empty_cache()
     # the whole hot path of an image, three images in flight, at the feature-sized logits: the headline's
     # loop with and without the flag (only the three N = 4096 injected layers are long enough to take it)
-    n_lanes, images = 3, 12
+    n_lanes, images = max(len(_LANE_STREAMS), 1), 12
     lanes = []
     for li in range(n_lanes):
         gen.manual_seed(4300 + li)
@@ -323,7 +329,7 @@ def block_skip_record(dev, compute):
             torch.cuda.synchronize()
             if timed:
                 rates[name] = images / (time.perf_counter() - t0)
-    rec["image"] = {"what": "hot path of one image as in `value`, 3 images in flight, attention tensors x3 (feature-sized logits)",
+    rec["image"] = {"what": "hot path of one image as in `value` (same lanes), attention tensors x3 (feature-sized logits)",
                     "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"], "ratio": rates["on"] / rates["off"]}
     del lanes
     torch.cuda.empty_cache()
@@ -370,7 +376,7 @@ def content_cache_record(dev, compute):
                              "partial_ms": tp * 1e3, "flop_computed_per_call": 8.0 * B * HEADS * N * N * d})
         del xq, q_cnt, kv, out, partial
         torch.cuda.empty_cache()
-    n_lanes, images = 3, 12
+    n_lanes, images = max(len(_LANE_STREAMS), 1), 12
     lanes = []
     t_partials = None
     for li in range(n_lanes):
@@ -406,7 +412,7 @@ def content_cache_record(dev, compute):
             if timed:
                 rates[name] = images / (time.perf_counter() - t0)
     part_bytes = sum(kv[2].partial.nbytes() for layer in lanes[0][2]["inj"] for _, kv in layer["feats"])
-    rec["image"] = {"what": "hot path of one image as in `value`, 3 images in flight; `cached`: the content blocks of its 294 "
+    rec["image"] = {"what": "hot path of one image as in `value` (same lanes); `cached`: the content blocks of its 294 "
                             "injected calls come from partials made once per content image",
                     "imgs_per_s_content_computed": rates["computed"], "imgs_per_s_content_cached": rates["cached"],
                     "ratio": rates["cached"] / rates["computed"],
@@ -666,6 +672,7 @@ def run_rank(args, world, rank, local):
                        "feature_store": ("key/value pairs pre-packed to bf16 operand layout at load time (%.2f GB per image)"
                                          if args.store == "packed" else "fp32 tensors (%.2f GB per image)") % (store_bytes / 1e9),
                        "images_per_rank": args.steps, "images_in_flight": n_lanes, "workloads_per_rank": n_lanes,
+                       "hardware_queues_per_process": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "ranks": world if dist is None else dist.get_world_size(),
                        "launch": ("kernel by kernel" if args.no_graph else "one HIP graph per image") if graph_error is None
                        else "kernel by kernel (graph capture failed: %s)" % graph_error[:120],

@@ -3,5 +3,5 @@
 B="timeout -k 10 200 python3 bench.py --no-e2e --no-cpu-baseline --no-block-skip --no-content-cache --steps 24 --warmup 6"
 val() { python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.1f imgs/s' % d['value'])"; }
 for q in 4 8; do for lanes in 3 5 6 7 8; do
-  echo "GPU_MAX_HW_QUEUES=$q lanes=$lanes: $(GPU_MAX_HW_QUEUES=$q $B --in-flight $lanes | val)" || exit 1
+  echo "GPU_MAX_HW_QUEUES=$q lanes=$lanes: $($B --hw-queues $q --in-flight $lanes | val)" || exit 1
 done; done
