@@ -55,8 +55,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "fp32"],
-                    help="bf16 operands; f16 = half-precision query/key operands in the long-sequence kernels; fp32 = split-bf16")
+    ap.add_argument("--compute", default="f16", choices=["bf16", "f16", "fp32"],
+                    help="f16 (the package default) = half-precision query/key operands, bf16 probabilities and values; "
+                         "bf16 = bf16 operands throughout; fp32 = split-bf16")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"], help="storage type of the query / latent tensors")
     ap.add_argument("--store", default="packed", choices=["packed", "tensors"],
                     help="feature store layout of the key/value pairs: the kernels' operand layout, or tensors")
@@ -64,6 +65,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end record (host UNet around the path)")
     ap.add_argument("--no-block-skip", action="store_true", help="skip the SID_FLAG_BLOCK_SKIP on/off record")
     ap.add_argument("--no-content-cache", action="store_true", help="skip the cached-content-block record")
+    ap.add_argument("--no-feature-scale", action="store_true", help="skip the record at feature-sized logits (both arithmetic modes)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the feature-store sweep record (load + sample over 8 triples)")
+    ap.add_argument("--no-default-queues", action="store_true", help="skip the child run with the runtime's default hardware queues")
+    ap.add_argument("--headline-only", action="store_true", help="print the line with `value` and `config` only (no side records)")
     ap.add_argument("--in-flight", type=int, default=4, help="images processed concurrently per GPU (one stream each)")
     ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process and its ranks (0: leave the environment alone)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying a HIP graph")
@@ -245,9 +250,22 @@ def kernel_records(w, compute):
     m = w["hf"][-1]
     t_hf = events_per_call(lambda: ops.hf_filter(m["h_cnt"][0], RATIO, skip=m["skip"], h=m["h"]), 300)
     hf_bytes = 16.0 * 320 * 64 * 64                     # three reads + one write of a (1,320,64,64) f32 map
+    # cold operands: 16 distinct (h_cnt, skip, h, out) sets, 336 MB in all, visited in turn, so that no launch finds
+    # its operands in the 256 MB Infinity Cache (the figure above replays one 21 MB set)
+    import torch
+    cold = [tuple(torch.randn(1, 320, 64, 64, device=m["skip"].device) for _ in range(4)) for _ in range(16)]
+    rot = [0]
+
+    def hf_cold():
+        a, b, c, o = cold[rot[0] % 16]
+        rot[0] += 1
+        ops.hf_filter(a, RATIO, skip=b, h=c, out=o)
+    t_hf_cold = events_per_call(hf_cold, 320)
+    del cold
     hf_kept = ops.hf_filter(m["h_cnt"][0], RATIO)       # HF(h_cnt) made once per content image: the sum alone is left
     t_sum = events_per_call(lambda: ops.residual_sum(m["skip"], m["h"], hf_kept), 300)
-    roof = {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true> injected attention N=4096 d=40 H=8 B=1",
+    roof = {"bound": "mfma", "kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true,%s,false> injected attention N=4096 d=40 H=8 B=1 (%s operands for q.k^T)"
+                      % (("true", "half-precision") if compute == "f16" else ("false", "bf16")),
             "achieved": flops / t_flash / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
             "frac": flops / t_flash / MFMA_PEAK, "kernel_ms": t_flash * 1e3, "algorithmic_flop": flops,
             "call_ms": t_call * 1e3, "call_frac": flops / t_call / MFMA_PEAK,
@@ -258,6 +276,9 @@ def kernel_records(w, compute):
     hf = {"bound": "hbm", "kernel": "sid_hf::hf2_kernel fused skip + h + HF(h_cnt), (1,320,64,64) f32", "kernel_ms": t_hf * 1e3,
           "achieved": hf_bytes / t_hf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hf_bytes / t_hf / HBM_PEAK,
           "algorithmic_bytes": hf_bytes,
+          "cache_assisted": True,
+          "cold": {"what": "the same launch over 16 operand sets in turn (336 MB > the 256 MB Infinity Cache): every byte from HBM",
+                   "kernel_ms": t_hf_cold * 1e3, "achieved": hf_bytes / t_hf_cold / 1e9, "frac": hf_bytes / t_hf_cold / HBM_PEAK},
           "cached": {"what": "skip + h + HF(h_cnt) with HF(h_cnt) kept per content image (sid_residual_sum): same bytes, no transform "
                              "(back-to-back calls on the same 21 MB: the Infinity Cache serves part of them, here as in the fused figure)",
                      "kernel_ms": t_sum * 1e3, "achieved": hf_bytes / t_sum / 1e9, "frac": hf_bytes / t_sum / HBM_PEAK}}
@@ -346,6 +367,74 @@ _LANE_STREAMS = []
 def lane_stream(dev, li):
     import torch
     return _LANE_STREAMS[li] if li < len(_LANE_STREAMS) else torch.cuda.Stream(device=dev)
+
+
+def feature_scale_record(dev, compute):
+    """The headline loop again on features twice as large (q, k, v of the attention tensors at sigma 2: logits
+    of the size real DDIM-inversion features produce), in both half-precision arithmetic modes, with the
+    error of one top-layer call against the f32-grade kernels beside each rate.  Not part of `value`."""
+    import torch
+    from style_transfer_amd import ops
+    sigma = 2.0
+    gen = torch.Generator(device=dev)
+    n_lanes, images = max(len(_LANE_STREAMS), 1), 12
+    rec = {"what": "hot path of one image as in `value` (same lanes, same graphs), attention tensors x2 (feature-sized logits)",
+           "feature_sigma": sigma, "modes": {}}
+    for mode in ("f16", "bf16"):
+        lanes = []
+        for li in range(n_lanes):
+            gen.manual_seed(6100 + li)
+            w = make_image_workload(dev, gen, torch.float32, "packed", mode, sigma=sigma)
+            st = lane_stream(dev, li)
+            with torch.cuda.stream(st):
+                run_image(w, mode, ops.FLAG_THROUGHPUT)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+                run_image(w, mode, ops.FLAG_THROUGHPUT)
+            lanes.append((st, graph, w))
+        rate = None
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(images):
+                st, graph, _ = lanes[i % n_lanes]
+                with torch.cuda.stream(st):
+                    graph.replay()
+            torch.cuda.synchronize()
+            if timed:
+                rate = images / (time.perf_counter() - t0)
+        # one call of the top injected layer against the f32-grade kernels on the same tensors
+        gen.manual_seed(6200)
+        rn = lambda *s: torch.randn(*s, device=dev, generator=gen) * sigma
+        N, d = 4096, 40
+        xq, feats = rn(1, N, HEADS * d), [rn(HEADS, N, d) for _ in range(7)]
+        mask = lanes[0][2]["inj"][-1]["mask"]
+        call = lambda c: ops.injected_attention(xq, *feats, mask, GAMMA, TEMP, d ** -0.5, HEADS, compute=c)
+        ref = call("fp32")
+        got = call(mode)
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        row = ((got - ref).abs().amax(-1) / ref.abs().amax(-1).clamp_min(1e-30)).max().item()
+        rec["modes"][mode] = {"imgs_per_s": rate, "rel_err_vs_f32_grade": err, "per_row_rel_err_vs_f32_grade": row}
+        del lanes, xq, feats, ref, got
+        torch.cuda.empty_cache()
+    return rec
+
+
+def default_queue_record(args):
+    """The headline loop in a child process that leaves GPU_MAX_HW_QUEUES alone (the runtime's default of four
+    hardware queues per process): what a caller who does not set the variable gets with the same lanes."""
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--hw-queues", "0", "--headline-only", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--compute", args.compute, "--io", args.io, "--store", args.store,
+           "--in-flight", str(args.in_flight)] + (["--no-graph"] if args.no_graph else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        js = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"what": "same loop, child process without GPU_MAX_HW_QUEUES (runtime default: 4 queues)", "value": js["value"],
+                "hardware_queues_per_process": js["hardware_queues_per_process"], "images_in_flight": js["images_in_flight"]}
+    except Exception as e:       # the side record must not take the line down
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def content_cache_record(dev, compute):
@@ -613,8 +702,18 @@ def run_rank(args, world, rank, local):
             dist.init_process_group("gloo")
         assert dist.get_world_size() == world
 
+    # which collectives ran for the first time inside the timed region (their first use sets up channels)
+    seen_ops, first_in_timed, clock = set(), [], {"on": False}
+
+    def note(op):
+        if dist is not None and op not in seen_ops:
+            seen_ops.add(op)
+            if clock["on"]:
+                first_in_timed.append(op)
+
     def barrier():
         if dist is not None:
+            note("barrier")
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -628,26 +727,50 @@ def run_rank(args, world, rank, local):
                 out = run_image(w, args.compute, kflags)
             return out.reshape(-1)[:4 * 64 * 64].clone()    # stand-in for the (1,4,64,64) latent, 64 KiB
 
+    def to_wire(t):
+        return t.cpu() if dist is not None and args.backend == "gloo" else t
+
     for i in range(args.warmup):
         one_image(i)
+    # Warm-up of the job's one collective, with the shape the timed gather will have: the first gather of a
+    # process group sets up its point-to-point channels, and the first all_reduce its ring; neither belongs
+    # to the timed region (with 20 images the region is under half a second).
+    if dist is not None:
+        dummy = to_wire(torch.zeros(args.steps, 4 * 64 * 64, device=dev))
+        note("gather")
+        sharding.gather_latents(dummy, dist, dst=0)
+        tw = torch.zeros(1, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        note("all_reduce")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     barrier()
+    clock["on"] = True
     t0 = time.perf_counter()
     latents = [one_image(i) for i in range(args.steps)]
     torch.cuda.synchronize()
-    mine = torch.stack(latents).float()
-    if dist is not None and args.backend == "gloo":
-        mine = mine.cpu()
+    t_images = time.perf_counter() - t0                    # this rank's own images, before the gather
+    mine = to_wire(torch.stack(latents).float())
+    note("gather")
     gathered = sharding.gather_latents(mine, dist, dst=0)  # the one collective of the job (RCCL gather)
     if rank == 0:
         assert gathered.shape[0] == world and gathered.shape[1] == args.steps
     barrier()
     elapsed = time.perf_counter() - t0
+    clock["on"] = False
+    rank_rates = [args.steps / t_images]
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine_rate = torch.tensor([args.steps / t_images], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        rates = [torch.zeros_like(mine_rate) for _ in range(world)]
+        dist.all_gather(rates, mine_rate)                  # after the clock has stopped
+        rank_rates = [float(r.item()) for r in rates]
 
-    if rank == 0:
+    if rank == 0 and args.headline_only:
+        print(json.dumps({"value": world * args.steps / elapsed, "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
+                          "hardware_queues_per_process": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                          "images_in_flight": n_lanes, "compute": args.compute}), flush=True)
+    elif rank == 0:
         roof, hf = kernel_records(lanes[0][3], args.compute)
         store_bytes = sum(kv.nbytes() if isinstance(kv, ops.PackedKV) else kv[0].numel() * kv[0].element_size() * 2
                           for layer in lanes[0][3]["inj"] for (_, kvs) in layer["feats"] for kv in kvs)
@@ -677,18 +800,27 @@ def run_rank(args, world, rank, local):
                        "launch": ("kernel by kernel" if args.no_graph else "one HIP graph per image") if graph_error is None
                        else "kernel by kernel (graph capture failed: %s)" % graph_error[:120],
                        "collective": "one gather of 64 KiB latents per image" if world > 1 else "none"},
+            # every rank's own rate over its images (before the gather): a straggler shows here, `value` divides by
+            # the slowest rank's whole region
+            "per_rank": {"imgs_per_s": rank_rates, "min": min(rank_rates), "max": max(rank_rates),
+                         "collectives_warmed_before_t0": sorted(seen_ops - set(first_in_timed)) if world > 1 else None,
+                         "first_use_collectives_in_timed_region": first_in_timed},
             "roofline": roof,
             "hf_filter": hf,
         }
         if world == 1:
             del lanes[1:]
             torch.cuda.empty_cache()
+            line["feature_scale"] = None if args.no_feature_scale else feature_scale_record(dev, args.compute)
             line["block_skip"] = None if args.no_block_skip else block_skip_record(dev, args.compute)
             line["content_cache"] = None if args.no_content_cache else content_cache_record(dev, args.compute)
             line["e2e"] = None if args.no_e2e else e2e_record(dev, args.compute, args.store)
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+            line["default_hw_queues"] = None if args.no_default_queues or args.hw_queues == 0 else default_queue_record(args)
         else:
             line["e2e"] = None
+            line["feature_scale"] = None
+            line["default_hw_queues"] = None
             line["block_skip"] = None
             line["content_cache"] = None
             line["cpu_baseline"] = None

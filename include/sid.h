@@ -37,13 +37,16 @@ extern "C" {
 #define SID_DTYPE_BF16 1
 
 /* arithmetic of the two matrix products inside the attention kernels */
-#define SID_COMPUTE_BF16 0  /* bf16 MFMA operands, f32 accumulate: <= 2e-2 relative */
+#define SID_COMPUTE_BF16 0  /* bf16 MFMA operands, f32 accumulate: <= 2e-2 relative at unit-variance q, k (see F16QK) */
 #define SID_COMPUTE_F32X3 1 /* split-bf16 (hi+lo) 3-product MFMA, f32-grade: <= 1e-3 relative */
 /* Half-precision (f16) operands for the logits product q k^T, bf16 for P V, f32 accumulate: the speed of
- * SID_COMPUTE_BF16 with eight times finer logits (<= 1e-2 relative also at feature-scale magnitudes,
- * where bf16 logits cost 2-3e-2).  Scaled queries and keys beyond +-65504 saturate.  Flash path only
- * (more than 256 keys), head dims 33-48 and 65-80 (else SID_ENOSYS), and
- * |logit scale * log2(e)| in [2^-10, 2^10] (else SID_EINVAL). */
+ * SID_COMPUTE_BF16 with eight times finer logits.  The error of a bf16-operand logit grows with |q||k|:
+ * <= 2e-2 relative at unit-variance features, 2.5-3.2e-2 at three times that (feature-sized logits), for
+ * any implementation that rounds q and k to bf16; this mode stays <= 1e-2 at every scale tested and is what
+ * the Python layer selects by default.  Scaled queries and keys beyond +-65504 saturate.  Every head dim and
+ * sequence length the bf16 mode serves; tensors stored as bf16 carry no more than bf16 holds, so for them the
+ * mode equals SID_COMPUTE_BF16.  More than 256 keys (the long-sequence kernels scale the queries before the
+ * product): |logit scale * log2(e)| must lie in [2^-10, 2^10], else SID_EINVAL. */
 #define SID_COMPUTE_F16QK 2
 
 /* memory layout of a (batch, heads, tokens, head_dim) tensor; head_dim is always contiguous */
@@ -195,10 +198,13 @@ int sid_injected_attn_fwd_cached(const void* x_q, const void* q_cnt,
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arguments and results as sid_injected_attn_fwd without the workspace pair: the scratch is a
  * static device array of SID_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the
- * process ends.  The call allocates and frees nothing (its first call on a device looks the array's
- * address up once).  A shape whose scratch need (sid_injected_attn_workspace_bytes) exceeds the array
+ * process ends.  The call allocates and frees nothing.  Its FIRST call on a device looks the array's
+ * address up (hipGetSymbolAddress, a runtime call that is not a stream operation): make that first call
+ * eagerly, outside HIP graph capture; every later call on the device only enqueues kernels and may be
+ * captured.  A shape whose scratch need for this call's decomposition (at most
+ * sid_injected_attn_workspace_bytes, which covers every decomposition of the shape) exceeds the array
  * is refused with SID_ENOMEM; 64 MiB covers B = 1, H = 8 at N = 4096, d = 40 and N = 1024, d = 80
- * in SID_COMPUTE_BF16.  All calls on one GPU share the array: calls that overlap in time on one GPU
+ * in SID_COMPUTE_BF16 and SID_COMPUTE_F16QK.  All calls on one GPU share the array: calls that overlap in time on one GPU
  * (different streams or threads) race; serialise them, or give each stream its own workspace through
  * sid_injected_attn_fwd.
  */
@@ -216,8 +222,10 @@ int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt,
 /*
  * Where the four block-skipping counters of the last sid_injected_attn_fwd[_packed] call with these
  * arguments sit in its workspace (byte offset of 4 x uint32: key-block segments dropped, content segments
- * reduced to their logits, such segments redone in full, segments seen), or -1 when the flag has no effect.
- * No counterpart in the reference: measurement and tests.
+ * reduced to their logits, such segments redone in full, segments seen), or -1 when the flag has no effect
+ * for the shape and mode.  A call also ignores the flag, and then leaves the counters unwritten, when its
+ * T or scale is not positive or T * scale * log2(e) < 2^-30: read the counters only after calls outside
+ * that range.  No counterpart in the reference: measurement and tests.
  */
 long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int compute, int flags, int packed);
 

@@ -14,6 +14,7 @@ them runs in libsid.so:
 """
 import math
 import os
+import warnings
 
 import torch
 from torch import nn
@@ -21,14 +22,14 @@ from torch import nn
 from . import ops
 from .mask import default_cache, mask_path_for
 
-_default_compute = "bf16"
+_default_compute = "f16"
 
 
 def set_default_compute(mode):
-    """'bf16': bf16 MFMA operands (<= 2e-2 rel.); 'f16': half-precision query/key operands where the
-    library has them (long sequences at head dims 33-48 and 65-80: the injected layers of SD-v1; <= 1e-2
-    also at feature-scale magnitudes, same speed), bf16 elsewhere; 'fp32': split-bf16 f32-grade products
-    (<= 1e-3)."""
+    """'f16' (the default): half-precision query/key operands in the logits product, bf16 probabilities and
+    values (<= 1e-2 rel. also at feature-scale magnitudes); 'bf16': bf16 operands throughout (<= 2e-2 at
+    unit-variance features, up to 3.2e-2 at three times that; 3 % faster on the longest layers);
+    'fp32': split-bf16 f32-grade products (<= 1e-3)."""
     global _default_compute
     if mode not in ("bf16", "f16", "fp32"):
         raise ValueError("compute mode must be 'bf16', 'f16' or 'fp32'")
@@ -36,16 +37,25 @@ def set_default_compute(mode):
 
 
 def resolve_compute(mode, n_keys, head_dim, logit_scale):
-    """The arithmetic a call runs in: 'f16' falls back to 'bf16' where SID_COMPUTE_F16QK has no kernel
-    (include/sid.h: head dims 33-48 and 65-80, more than 256 keys, |scale * log2(e)| in [2^-10, 2^10])."""
+    """The arithmetic a call runs in: 'f16' falls back to 'bf16' where SID_COMPUTE_F16QK refuses the call
+    (include/sid.h: more than 256 keys and |scale * log2(e)| outside [2^-10, 2^10]: the long-sequence
+    kernels keep the scaled queries in half precision)."""
     if mode != "f16":
         return mode
     c2 = abs(logit_scale) * 1.4426950408889634
-    served = (33 <= head_dim <= 48 or 65 <= head_dim <= 80) and n_keys > 256 and 2.0 ** -10 <= c2 <= 2.0 ** 10
+    served = n_keys <= 256 or 2.0 ** -10 <= c2 <= 2.0 ** 10
     return "f16" if served else "bf16"
 
 
+def resolve_injected_compute(mode, n_keys, head_dim, T, scale):
+    """resolve_compute for the three-block call: its style blocks scale by T * scale, its content block by scale."""
+    mode = resolve_compute(mode, n_keys, head_dim, scale)
+    return resolve_compute(mode, n_keys, head_dim, T * scale)
+
+
 class CrossAttention(nn.Module):
+    _warned_bypass = False
+
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
         super().__init__()
         inner_dim = dim_head * heads
@@ -135,6 +145,11 @@ class CrossAttention(nn.Module):
                 self.k, self.v = k_injected, v_injected
                 self._q, self._q_lazy = None, (lambda: q_cnt * gamma + self._split(xq) * (1. - 0.5))
                 partial = getattr(cnt_k_injected, "partial", None)
+                if partial is not None and partial.q_ptr != q_cnt.data_ptr() and not CrossAttention._warned_bypass:
+                    CrossAttention._warned_bypass = True
+                    warnings.warn("a cached content block is not used: the call's content query is not the tensor the block "
+                                  "was made from (a dtype or device copy: store the features in the model's dtype); "
+                                  "computing all three blocks")
                 if partial is not None and partial.q_ptr == q_cnt.data_ptr() and partial.scale == float(self.scale):
                     # the store computed the content block of this (timestep, layer) when it was loaded
                     # (FeatureStore.pack(cache_content=True)): only the two style blocks are left
@@ -145,7 +160,7 @@ class CrossAttention(nn.Module):
                 out = ops.injected_attention_packed(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, cnt_k_injected, m,
                                                     gamma, T, self.scale, self.heads, q_self_coef=0.5,
                                                     flags=self.kernel_flags)
-                self._review_block_skip(xq, k_injected.compute, True)
+                self._review_block_skip(xq, k_injected.compute, True, T)
                 return self.to_out(out)
             feats = [q_injected, k_injected, v_injected, sty2_k_injected, sty2_v_injected, cnt_k_injected,
                      cnt_v_injected]
@@ -188,15 +203,13 @@ class CrossAttention(nn.Module):
     # time another implementation inside the same network; the package itself has no other path.)
     def _injected(self, xq, feats, m, gamma, T, compute):
         d = xq.shape[-1] // self.heads
-        compute = resolve_compute(compute, xq.shape[1], d, min(abs(T), 1.0) * self.scale if T else self.scale)
-        if compute == "f16":
-            compute = resolve_compute(compute, xq.shape[1], d, max(abs(T), 1.0) * self.scale)
+        compute = resolve_injected_compute(compute, xq.shape[1], d, T, self.scale)
         out = ops.injected_attention(xq, *feats, m, gamma, T, self.scale, self.heads, q_self_coef=0.5, compute=compute,
                                      flags=self.kernel_flags)
-        self._review_block_skip(xq, compute, False)
+        self._review_block_skip(xq, compute, False, T)
         return out
 
-    def _review_block_skip(self, xq, compute, packed):
+    def _review_block_skip(self, xq, compute, packed, T):
         """skip_policy "auto": keep ops.FLAG_BLOCK_SKIP on this layer only if the call just made dropped a style
         block for at least half of its query groups (where nothing can be dropped the flag costs about a
         fifth of the call).  Decided once per arming (run.py arms it per image); never during graph capture."""
@@ -204,8 +217,8 @@ class CrossAttention(nn.Module):
             return
         if torch.cuda.is_current_stream_capturing():
             return
-        counts = ops.skip_counts(xq, self.heads, compute, self.kernel_flags, packed)
-        if counts is None or 2 * counts[0] < counts[3]:
+        counts = ops.skip_counts(xq, self.heads, compute, self.kernel_flags, packed, T=T, scale=self.scale)
+        if counts is None or counts[3] == 0 or 2 * counts[0] < counts[3]:
             self.kernel_flags &= ~ops.FLAG_BLOCK_SKIP
         self.skip_policy = "fixed"
 

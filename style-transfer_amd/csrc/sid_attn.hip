@@ -42,10 +42,10 @@ inline float clamp_scale(float c) {
 }
 
 // SID_COMPUTE_F16QK keeps the scaled queries in half precision: the logit scale must leave them inside
-// half's normal range, and a kernel instance must exist for the head dim.
+// half's normal range (the short-sequence kernels scale after the product and have no such limit).
 int check_f16qk(int DKS, int DVB, int d, const float* c2, int n) {
     if (!f16qk_instance(DKS, DVB))
-        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves head dims 33-48 and 65-80 (got %d); use SID_COMPUTE_BF16", d);
+        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK has no kernel for head_dim %d; use SID_COMPUTE_BF16", d);
     for (int i = 0; i < n; ++i)
         if (!(std::fabs(c2[i]) >= 0x1p-10f && std::fabs(c2[i]) <= 0x1p10f))
             return sid::fail(SID_EINVAL, "SID_COMPUTE_F16QK needs |logit scale * log2(e)| in [2^-10, 2^10] (got %g): "
@@ -859,7 +859,7 @@ extern "C" int sid_pack_kv(const void* k, const void* v, void* image, size_t ima
     if (im.bytes > image_bytes)
         return sid::fail(SID_ENOMEM, "image of %zu bytes is smaller than the %zu required", image_bytes, im.bytes);
     if (compute == SID_COMPUTE_F16QK && !f16qk_instance(g.DKS, g.DVB))
-        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves head dims 33-48 and 65-80 (got %d); use SID_COMPUTE_BF16", d);
+        return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK has no kernel for head_dim %d; use SID_COMPUTE_BF16", d);
     PackParams pp = {};
     pp.njobs = 2; pp.H = H; pp.d = d; pp.DKS = g.DKS; pp.DVB = g.DVB; pp.in_bf16 = dtype == SID_DTYPE_BF16;
     pp.f16_rows = compute == SID_COMPUTE_F16QK;
@@ -1131,15 +1131,12 @@ extern "C" int sid_plain_attn_fwd(const void* q, const void* k, const void* v, v
     const bool x3 = compute == SID_COMPUTE_F32X3;
     constexpr float LOG2E = 1.4426950408889634f;
     if (use_small_path(Nk, d)) {
-        if (compute == SID_COMPUTE_F16QK)
-            return sid::fail(SID_ENOSYS, "SID_COMPUTE_F16QK serves key sequences longer than 256 (got %d): use "
-                             "SID_COMPUTE_BF16 or SID_COMPUTE_F32X3 for this call", Nk);
         if (!stg.flash) return SID_OK;
         long long qs[3], ks[3];
         layout_strides(q_layout, H, Nq, d, qs);
         layout_strides(kv_layout, H, Nk, d, ks);
         return launch_small_attn(q, k, v, out, B, H, Nq, Nk, d, logit_scale * LOG2E, qs, ks, dtype == SID_DTYPE_BF16, x3, stream,
-                                 (flags & SID_FLAG_THROUGHPUT) != 0);
+                                 (flags & SID_FLAG_THROUGHPUT) != 0, compute == SID_COMPUTE_F16QK);
     }
     Geometry g;
     rc = make_geometry(B, H, Nq, Nk, d, 1, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);

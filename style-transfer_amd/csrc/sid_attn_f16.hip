@@ -1,5 +1,5 @@
 // Instantiation unit: attention kernels with half-precision (f16) query / key operands and bf16
-// probability / value operands (SID_COMPUTE_F16QK), head dims 33-48 and 65-80.
+// probability / value operands (SID_COMPUTE_F16QK), every head-dim class.
 #include "sid_attn_kernel.hpp"
 
 namespace sid_attn {

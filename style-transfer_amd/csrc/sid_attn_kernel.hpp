@@ -177,7 +177,8 @@ int launch_merge(const MergeParams& mp, hipStream_t stream);
 // directly (element strides {batch, head, token}), needs no workspace.
 bool small_attn_supported(int Nk, int d);
 int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
-                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu = false);
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu = false,
+                      bool qk16 = false);
 
 #if defined(__HIPCC__)
 
@@ -1280,9 +1281,8 @@ int launch_flash_nw(const FlashParams& fp, const Geometry& g, hipStream_t stream
     }
 }
 
-// The half-precision logits mode is instantiated for the head dims of the SD-v1 injected layers:
-// 33-48 (DKS 3, DVB 2) and 65-80 (DKS 5, DVB 3).
-constexpr bool f16qk_instance(int DKS, int DVB) { return (DKS == 3 && DVB == 2) || (DKS == 5 && DVB == 3); }
+// The half-precision logits mode is instantiated for every head-dim class the bf16 mode serves.
+constexpr bool f16qk_instance(int DKS, int DVB) { return DKS > 0 && DVB > 0; }
 
 template <bool X3, bool QK16 = false>
 int launch_flash(const FlashParams& fp, const Geometry& g, hipStream_t stream) {

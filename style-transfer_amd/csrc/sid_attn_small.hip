@@ -71,7 +71,8 @@ struct RowFrag {                 // raw registers of one 8-element fragment
             for (int j = 0; j < 8; ++j) raw[j] = ld<BF16IN>(base, off + min(d0 + j, d - 1));
         }
     }
-    template <bool X3>
+    // QK16 (f32 input only): the fragment holds IEEE halves (saturated), typed bf16x8 like every fragment
+    template <bool X3, bool QK16 = false>
     __device__ __forceinline__ void finish(bool row_ok, int d0, int d, bf16x8& hi, bf16x8& lo) const {
         if (MODE == 2) {
             const bool ok = row_ok && d0 + 8 <= d;
@@ -80,20 +81,28 @@ struct RowFrag {                 // raw registers of one 8-element fragment
             if (X3) lo = as_bf16x8(z);
             return;
         }
+        f16x8 hv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool ok = row_ok && (MODE == 1 ? d0 + 4 * (j >> 2) + 4 <= d : d0 + j < d);
             const float x = ok ? raw[j] : 0.f;
-            hi[j] = (__bf16)x;
-            if (X3) lo[j] = (__bf16)(x - (float)hi[j]);
+            if (QK16) {
+                hv[j] = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+            } else {
+                hi[j] = (__bf16)x;
+                if (X3) lo[j] = (__bf16)(x - (float)hi[j]);
+            }
         }
+        if (QK16) hi = __builtin_bit_cast(bf16x8, hv);
     }
 };
 
 // NKT: compile-time bound on the key tiles (2, 4 or 8), so that the V gather is one straight run of
 // loads; tiles in [nkt, NKT) read clamped addresses and are not used.
-template <int DKS, int NKT, bool X3, bool BF16IN, int MODE>
+// QK16: half-precision operands for the logits product (f32 input, not with X3).
+template <int DKS, int NKT, bool X3, bool BF16IN, int MODE, bool QK16 = false>
 __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(SmallParams P) {
+    static_assert(!QK16 || (!X3 && !BF16IN), "half-precision logits operands: f32 input, single product");
     __shared__ float sm_m[kSmallMaxTiles][32];
     __shared__ float sm_l[kSmallMaxTiles][32];
     __shared__ __attribute__((aligned(16))) u32x4 sm_p[(X3 ? 2 : 1) * kSmallMaxTiles * 2 * 64];
@@ -129,9 +138,9 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
 #pragma unroll
         for (int s = 0; s < DKS; ++s) {
             bf16x8 kh, kl, qh, ql;
-            kr[s].template finish<X3>(krow < P.Nk, 16 * s + 8 * hh, d, kh, kl);
-            qr[s].template finish<X3>(qrow < P.Nq, 16 * s + 8 * hh, d, qh, ql);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, S, 0, 0, 0);
+            kr[s].template finish<X3, QK16>(krow < P.Nk, 16 * s + 8 * hh, d, kh, kl);
+            qr[s].template finish<X3, QK16>(qrow < P.Nq, 16 * s + 8 * hh, d, qh, ql);
+            S = mfma_qk<QK16>(kh, qh, S);
             if (X3) {
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, S, 0, 0, 0);
@@ -276,8 +285,10 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_kernel(Smal
 // ------------------------------------------------------------------------------------------
 constexpr int kUnit = 528;
 
-template <int DKS, int MODE, int QT>
+// QK16 (MODE 1 only): the K and Q images hold IEEE halves, the logits MFMA is the f16 form; V and P stay bf16.
+template <int DKS, int MODE, int QT, bool QK16 = false>
 __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(SmallParams P, int vst, int p_off, int st_off) {
+    static_assert(!QK16 || MODE == 1, "half-precision logits operands need f32 input");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EPP = MODE == 1 ? 4 : 8;           // elements per 16-byte piece
     constexpr int PRF = 16 * DKS / EPP;              // pieces per padded row
@@ -311,9 +322,18 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
         if (MODE == 1) raw = __builtin_bit_cast(u32x4, *(const f32x4*)((const float*)base + rowoff + 4 * c));
         else raw = *(const u32x4*)((const __bf16*)base + rowoff + 8 * c);
     };
-    auto to_bf16 = [&](const u32x4& raw, bool ok, unsigned (&o)[4]) {       // MODE 1 fills o[0..1], MODE 2 o[0..3]
+    // `half`: a row of the logits product in QK16 mode (K, Q): IEEE halves, saturated; V is always bf16
+    auto to_bf16 = [&](const u32x4& raw, bool ok, unsigned (&o)[4], bool half = false) {       // MODE 1 fills o[0..1], MODE 2 o[0..3]
         if (MODE == 1) {
             const f32x4 f = __builtin_bit_cast(f32x4, raw);
+            if (QK16 && half) {
+                typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+                auto sat = [](float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); };
+                f16x2 lo2 = {sat(f[0]), sat(f[1])}, hi2 = {sat(f[2]), sat(f[3])};
+                o[0] = ok ? __builtin_bit_cast(unsigned, lo2) : 0u;
+                o[1] = ok ? __builtin_bit_cast(unsigned, hi2) : 0u;
+                return;
+            }
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
             bf16x2 lo2 = {(__bf16)f[0], (__bf16)f[1]}, hi2 = {(__bf16)f[2], (__bf16)f[3]};
             o[0] = ok ? __builtin_bit_cast(unsigned, lo2) : 0u;
@@ -359,7 +379,7 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
             if (f < QT * NPT) {
                 const int row = f / PRF, col = f % PRF;
                 unsigned o[4];
-                to_bf16(qraw[i], col < pr, o);
+                to_bf16(qraw[i], col < pr, o, true);
                 store_piece(qb + (row >> 5) * TILE_BYTES + frag_addr(row & 31, col), o);
             }
         }
@@ -371,7 +391,7 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
         for (int i = 0; i < ITERS; ++i) {
             const int f = i * 64 + lane, row = f / PRF, col = f % PRF;
             unsigned o[4];
-            to_bf16(kraw[i], col < pr, o);
+            to_bf16(kraw[i], col < pr, o, true);
             store_piece(kq + wave * TILE_BYTES + frag_addr(row, col), o);
         }
     }
@@ -402,7 +422,7 @@ __global__ void __launch_bounds__(kSmallMaxTiles * 64, 1) small_attn_lds_kernel(
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 const bf16x8 qf = as_bf16x8(*(const u32x4*)(qb + t * TILE_BYTES + (2 * s + hh) * kUnit + r * 16));
-                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf, S[t], 0, 0, 0);
+                S[t] = mfma_qk<QK16>(kf, qf, S[t]);
             }
         }
 #pragma unroll
@@ -533,9 +553,9 @@ SmallLds small_lds_layout(const SmallParams& p, int QT) {
     return L;
 }
 
-template <int DKS, int MODE, int QT>
+template <int DKS, int MODE, int QT, bool QK16>
 int launch_small_lds_qt(const SmallParams& p, int BH, int waves, const SmallLds& L, hipStream_t stream) {
-    constexpr auto kern = small_attn_lds_kernel<DKS, MODE, QT>;
+    constexpr auto kern = small_attn_lds_kernel<DKS, MODE, QT, QK16>;
     const int rc = sid::allow_dynamic_lds<kern>(160 * 1024);
     if (rc != SID_OK) return rc;
     const int nqg = (p.NQT + QT - 1) / QT;
@@ -544,7 +564,7 @@ int launch_small_lds_qt(const SmallParams& p, int BH, int waves, const SmallLds&
     return SID_OK;
 }
 
-template <int DKS, int MODE>
+template <int DKS, int MODE, bool QK16 = false>
 int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream) {
     // Two query tiles per workgroup halve the work of a call and add a quarter to the time of one workgroup
     // (measured, one -> two tiles: (256,256,160) 11.1 -> 13.9 us at one image, 21.4 -> 18.6 us at four;
@@ -558,12 +578,14 @@ int launch_small_lds(const SmallParams& p, int BH, int waves, hipStream_t stream
     const bool full = p.two_tiles || wgs >= 512 || (wgs >= 256 && p.Nk >= 128);
     const bool want = (e && e[0] == '2') || (!(e && e[0] == '1') && full);
     if (want && p.NQT >= 2 && two.bytes <= 160 * 1024)
-        return launch_small_lds_qt<DKS, MODE, 2>(p, BH, waves, two, stream);
-    return launch_small_lds_qt<DKS, MODE, 1>(p, BH, waves, small_lds_layout<DKS>(p, 1), stream);
+        return launch_small_lds_qt<DKS, MODE, 2, QK16>(p, BH, waves, two, stream);
+    return launch_small_lds_qt<DKS, MODE, 1, QK16>(p, BH, waves, small_lds_layout<DKS>(p, 1), stream);
 }
 
+// qk16 with bf16 input runs the bf16 kernels: a bf16 value is a half value wherever half's range holds it,
+// so the logits product gains nothing from the conversion.
 template <int DKS, int NKT, bool X3>
-int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStream_t stream) {
+int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, bool qk16, hipStream_t stream) {
     const dim3 grid((unsigned)(BH * p.NQT)), block(waves * 64);
     auto al = [](const void* ptr, long long a, long long b, long long c, int m) {
         return ((uintptr_t)ptr & 15) == 0 && a % m == 0 && b % m == 0 && c % m == 0;
@@ -572,8 +594,18 @@ int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStre
     const bool vec = p.d % m == 0 && al(p.q, p.qsb, p.qsh, p.qsn, m) && al(p.k, p.ksb, p.ksh, p.ksn, m) &&
                      ((uintptr_t)p.v & 15) == 0;
     const char* e = getenv("SID_TUNE_SMALL_DIRECT");       // measurement and tests only
-    if (!X3 && vec && !(e && e[0] == '1'))
-        return bf16in ? launch_small_lds<DKS, 2>(p, BH, waves, stream) : launch_small_lds<DKS, 1>(p, BH, waves, stream);
+    if (!X3 && vec && !(e && e[0] == '1')) {
+        if (bf16in) return launch_small_lds<DKS, 2>(p, BH, waves, stream);
+        return qk16 ? launch_small_lds<DKS, 1, true>(p, BH, waves, stream) : launch_small_lds<DKS, 1>(p, BH, waves, stream);
+    }
+    if constexpr (!X3) {
+        if (qk16 && !bf16in) {
+            if (vec) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, false, 1, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, false, false, 0, true>), grid, block, 0, stream, p);
+            SID_CHECK_HIP(hipGetLastError());
+            return SID_OK;
+        }
+    }
     if (bf16in) {
         if (vec) hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 2>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((small_attn_kernel<DKS, NKT, X3, true, 0>), grid, block, 0, stream, p);
@@ -586,16 +618,16 @@ int launch_small_x(const SmallParams& p, int BH, int waves, bool bf16in, hipStre
 }
 
 template <int DKS, int NKT>
-int launch_small_inst(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
-    return x3 ? launch_small_x<DKS, NKT, true>(p, BH, waves, bf16in, stream)
-              : launch_small_x<DKS, NKT, false>(p, BH, waves, bf16in, stream);
+int launch_small_inst(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, bool qk16, hipStream_t stream) {
+    return x3 ? launch_small_x<DKS, NKT, true>(p, BH, waves, bf16in, false, stream)
+              : launch_small_x<DKS, NKT, false>(p, BH, waves, bf16in, qk16, stream);
 }
 
 template <int DKS>
-int launch_small_dks(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, hipStream_t stream) {
-    if (p.nkt <= 2) return launch_small_inst<DKS, 2>(p, BH, waves, x3, bf16in, stream);
-    if (p.nkt <= 4) return launch_small_inst<DKS, 4>(p, BH, waves, x3, bf16in, stream);
-    return launch_small_inst<DKS, 8>(p, BH, waves, x3, bf16in, stream);
+int launch_small_dks(const SmallParams& p, int BH, int waves, bool x3, bool bf16in, bool qk16, hipStream_t stream) {
+    if (p.nkt <= 2) return launch_small_inst<DKS, 2>(p, BH, waves, x3, bf16in, qk16, stream);
+    if (p.nkt <= 4) return launch_small_inst<DKS, 4>(p, BH, waves, x3, bf16in, qk16, stream);
+    return launch_small_inst<DKS, 8>(p, BH, waves, x3, bf16in, qk16, stream);
 }
 
 }  // namespace
@@ -603,7 +635,8 @@ int launch_small_dks(const SmallParams& p, int BH, int waves, bool x3, bool bf16
 bool small_attn_supported(int Nk, int d) { return Nk <= 32 * kSmallMaxTiles && (d + 31) / 32 <= kSmallMaxTiles && d <= 160; }
 
 int launch_small_attn(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int d,
-                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu) {
+                      float c2, const long long qs[3], const long long ks[3], bool bf16io, bool x3, hipStream_t stream, bool shared_gpu,
+                      bool qk16) {
     SmallParams p = {};
     p.two_tiles = shared_gpu;
     p.q = q; p.k = k; p.v = v; p.out = out;
@@ -614,13 +647,13 @@ int launch_small_attn(const void* q, const void* k, const void* v, void* out, in
     const int waves = p.nkt > p.ndv ? p.nkt : p.ndv;
     const int dks = (d + 15) / 16;
     switch (dks) {
-        case 1: case 2: return launch_small_dks<2>(p, B * H, waves, x3, bf16io, stream);
-        case 3: return launch_small_dks<3>(p, B * H, waves, x3, bf16io, stream);
-        case 4: return launch_small_dks<4>(p, B * H, waves, x3, bf16io, stream);
-        case 5: return launch_small_dks<5>(p, B * H, waves, x3, bf16io, stream);
-        case 6: return launch_small_dks<6>(p, B * H, waves, x3, bf16io, stream);
-        case 7: case 8: return launch_small_dks<8>(p, B * H, waves, x3, bf16io, stream);
-        case 9: case 10: return launch_small_dks<10>(p, B * H, waves, x3, bf16io, stream);
+        case 1: case 2: return launch_small_dks<2>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 3: return launch_small_dks<3>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 4: return launch_small_dks<4>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 5: return launch_small_dks<5>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 6: return launch_small_dks<6>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 7: case 8: return launch_small_dks<8>(p, B * H, waves, x3, bf16io, qk16, stream);
+        case 9: case 10: return launch_small_dks<10>(p, B * H, waves, x3, bf16io, qk16, stream);
     }
     return sid::fail(SID_ENOSYS, "head_dim %d has no short-sequence kernel", d);
 }

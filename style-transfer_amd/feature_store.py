@@ -10,7 +10,10 @@ are decoded by `torch.load(..., weights_only=True)` onto the requested device, s
 a CUDA machine loads on ROCm (or CPU) and a file that is not a feature list is refused.
 """
 import io
+import json
+import os
 import pickle
+import struct
 
 import torch
 
@@ -139,28 +142,34 @@ def load_residuals_file(path, device="cuda"):
 
 class FeatureStore:
     """The three feature lists of one (content, character style, background style) triple, resident
-    on one device, and the merged per-step dicts the UNet consumes (run_ori.py:36-75, 235)."""
+    on one device, and the merged per-step dicts the UNet consumes (run_ori.py:36-75, 235).
+    `back` None: a (content, style) pair, the single-style path (hf_run.py:40-68, 383-455)."""
 
-    def __init__(self, cnt, char, back):
+    def __init__(self, cnt, char, back=None):
         self.cnt, self.char, self.back = cnt, char, back
+
+    def lists(self):
+        return tuple(f for f in (self.cnt, self.char, self.back) if f is not None)
 
     @classmethod
     def load(cls, precomputed_dir, cnt_base, char_base, back_base, device="cuda", dtype=None, cnt=None):
         """`cnt`: the content list of an earlier triple with the same content image, as that triple's store
         left it (loaded, possibly packed and carrying its cached content blocks), instead of the file."""
-        import os
         rd = lambda name: load_feature_file(os.path.join(precomputed_dir, name), device, dtype)
-        return cls(rd(cnt_base + "_cnt.pkl") if cnt is None else cnt, rd(char_base + "_sty.pkl"), rd(back_base + "_sty.pkl"))
+        return cls(rd(cnt_base + "_cnt.pkl") if cnt is None else cnt, rd(char_base + "_sty.pkl"),
+                   rd(back_base + "_sty.pkl") if back_base is not None else None)
 
     def z_enc(self):
         """The fully inverted latents (entry 0), cloned as run_ori.py:172,191,210 does."""
-        return tuple(torch.clone(f[0]["z_enc"]) for f in (self.cnt, self.char, self.back))
+        return tuple(torch.clone(f[0]["z_enc"]) for f in self.lists())
 
     def merged(self, opt, start_step=49):
-        from .features import feat_merge_2sty
+        from .features import feat_merge, feat_merge_2sty
+        if self.back is None:
+            return feat_merge(opt, self.cnt, self.char, start_step=start_step)
         return feat_merge_2sty(opt, self.cnt, self.char, self.back, start_step=start_step)
 
-    def pack(self, heads=8, compute="bf16", cache_content=False):
+    def pack(self, heads=8, compute="f16", cache_content=False, T=None):
         """Convert every key/value pair of the three lists to the attention kernels' operand layout
         (ops.pack_kv), in place: `..._self_attn_k` and `..._self_attn_v` of a block then hold ONE
         PackedKV object and the two tensors are dropped.  Done once per feature file, it removes the
@@ -171,33 +180,21 @@ class FeatureStore:
         (ops.content_partial: it reads q, k, v of the content file only) and attach it to the content
         pair; the attention calls then compute the two style blocks alone.  Worth it when the content
         list is reused for several style pairs (pass it to the next FeatureStore.load as `cnt`): the
-        partials cost what one image's content blocks cost, 0.66 GB per content image at SD-v1 sizes."""
-        from . import ops
-        for feats in (self.cnt, self.char, self.back):
-            for entry in feats:
-                for key in [k for k in entry if k.endswith("_self_attn_k") and torch.is_tensor(entry[k])]:
-                    vkey = key[:-1] + "v"
-                    d = entry[key].shape[-1]
-                    # half-precision operands exist for head dims 33-48 and 65-80; other layers take bf16
-                    mode = "bf16" if compute == "f16" and not (33 <= d <= 48 or 65 <= d <= 80) else compute
-                    kv = ops.pack_kv(entry[key].contiguous(), entry[vkey].contiguous(), heads, mode)
-                    entry[key] = entry[vkey] = kv
+        partials cost what one image's content blocks cost, 0.66 GB per content image at SD-v1 sizes.
+        T: the temperature the calls will use (default: the file's own config['T']); with compute 'f16' a
+        layer whose logit scales the half-precision mode refuses is packed for bf16 operands instead."""
+        if self.back is None:
+            raise ValueError("pre-packed key/value pairs serve the mask-based two-style attention; a single-style "
+                             "store stays unpacked")
+        for feats in self.lists():
+            pack_feature_list(feats, heads, compute, T)
         if cache_content:
-            jobs = []
-            for entry in self.cnt:
-                for key in [k for k in entry if k.endswith("_self_attn_k") and isinstance(entry[k], ops.PackedKV)]:
-                    kv, qkey = entry[key], key[:-1] + "q"
-                    if kv.partial is None:
-                        # the partial remembers the tensor it was made from: the call must pass this very one
-                        q = entry[qkey] = entry[qkey].contiguous()
-                        jobs.append((q, kv, q.shape[-1] ** -0.5))
-            for (_, kv, _), partial in zip(jobs, ops.content_partials(jobs, heads)):
-                kv.partial = partial
+            cache_content_blocks(self.cnt, heads)
         return self
 
     def nbytes(self):
         seen, total = set(), 0
-        for f in (self.cnt, self.char, self.back):
+        for f in self.lists():
             for e in f:
                 for v in e.values():
                     if torch.is_tensor(v):
@@ -206,3 +203,165 @@ class FeatureStore:
                         seen.add(id(v))
                         total += v.nbytes() + (v.partial.nbytes() if v.partial is not None else 0)
         return total
+
+
+def pack_feature_list(feats, heads=8, compute="f16", T=None):
+    """FeatureStore.pack for one list, in place (an already packed entry is left alone)."""
+    from . import ops
+    from .attention import resolve_injected_compute
+    for entry in feats:
+        for key in [k for k in entry if k.endswith("_self_attn_k") and torch.is_tensor(entry[k])]:
+            vkey = key[:-1] + "v"
+            n, d = entry[key].shape[-2:]
+            temp = T if T is not None else (entry.get("config") or {}).get("T", 1.0)
+            mode = resolve_injected_compute(compute, n, d, temp, d ** -0.5)
+            kv = ops.pack_kv(entry[key].contiguous(), entry[vkey].contiguous(), heads, mode)
+            entry[key] = entry[vkey] = kv
+    return feats
+
+
+def cache_content_blocks(cnt_feats, heads=8):
+    """Attach the content block (ops.content_partial) of every (timestep, layer) to the packed content list."""
+    from . import ops
+    jobs = []
+    for entry in cnt_feats:
+        for key in [k for k in entry if k.endswith("_self_attn_k") and isinstance(entry[k], ops.PackedKV)]:
+            kv, qkey = entry[key], key[:-1] + "q"
+            if kv.partial is None:
+                # the partial remembers the tensor it was made from: the call must pass this very one
+                q = entry[qkey] = entry[qkey].contiguous()
+                jobs.append((q, kv, q.shape[-1] ** -0.5))
+    for (_, kv, _), partial in zip(jobs, ops.content_partials(jobs, heads)):
+        kv.partial = partial
+    return cnt_feats
+
+
+# ------------------------------------------------------------------------------------------------
+# Packed side-car: `{base}_cnt.sidpack` / `{base}_sty.sidpack` beside the pickle
+# ------------------------------------------------------------------------------------------------
+# What a packed feature list holds in HBM, written as it lies there: a JSON header and one flat payload,
+# every item 256-byte aligned, every list entry a contiguous byte range.  Reading it executes nothing and
+# converts nothing: a range goes from the file into pinned host memory and from there into one device
+# buffer that the entry's tensors and key/value images are views of.  A style list keeps only what the
+# attention reads (its key/value images and the inverted latent of entry 0): a third of the pickle.
+# No counterpart in the reference (run_ori.py:168-222 unpickles 3.5 GB per file for every triple).
+SIDECAR_MAGIC = b"SIDPACK1"
+SIDECAR_ALIGN = 256
+_TORCH_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
+
+
+def sidecar_path(pkl_path):
+    return os.path.splitext(pkl_path)[0] + ".sidpack"
+
+
+def _source_stamp(pkl_path):
+    st = os.stat(pkl_path)
+    return {"name": os.path.basename(pkl_path), "size": st.st_size, "mtime_ns": st.st_mtime_ns}
+
+
+def write_sidecar(path, feats, role, heads, compute, pkl_path=None):
+    """`feats`: a feature list as pack_feature_list leaves it (key/value pairs as PackedKV).  role "sty"
+    drops the queries.  Written to a temporary name and renamed, so a reader never sees half a file."""
+    from . import ops
+    entries, blobs, off = [], [], 0
+    for entry in feats:
+        meta, seen = {"config": entry.get("config"), "items": {}, "begin": off}, {}
+        for k, v in entry.items():
+            if k == "config" or (role == "sty" and k.endswith("_self_attn_q")):
+                continue
+            if isinstance(v, ops.PackedKV):
+                if id(v) in seen:
+                    meta["items"][k] = {"kind": "same", "as": seen[id(v)]}
+                    continue
+                seen[id(v)] = k
+                raw = v.image
+                item = {"kind": "kv", "B": v.B, "H": v.H, "N": v.N, "d": v.d, "compute": int(v.compute)}
+            elif torch.is_tensor(v):
+                raw = v.contiguous()
+                item = {"kind": "tensor", "dtype": str(v.dtype).replace("torch.", ""), "shape": list(v.shape)}
+                if item["dtype"] not in _TORCH_DTYPES:
+                    raise ValueError("side-car: %s has dtype %s" % (k, v.dtype))
+            else:
+                raise ValueError("side-car: entry %r is neither a tensor nor a packed key/value pair" % k)
+            nbytes = raw.numel() * raw.element_size()
+            item["offset"], item["nbytes"] = off, nbytes
+            meta["items"][k] = item
+            blobs.append((off, raw))
+            off = (off + nbytes + SIDECAR_ALIGN - 1) // SIDECAR_ALIGN * SIDECAR_ALIGN
+        meta["end"] = off
+        entries.append(meta)
+    header = {"version": 1, "role": role, "heads": heads, "compute": compute, "entries": entries, "payload_bytes": off,
+              "source": _source_stamp(pkl_path) if pkl_path else None}
+    hb = json.dumps(header).encode()
+    start = (len(SIDECAR_MAGIC) + 8 + len(hb) + 4095) // 4096 * 4096
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(SIDECAR_MAGIC + struct.pack("<Q", len(hb)) + hb)
+        for o, raw in blobs:
+            f.seek(start + o)
+            f.write(memoryview(raw.detach().cpu().contiguous().view(torch.uint8).reshape(-1).numpy()))
+        f.truncate(start + off)
+    os.replace(tmp, path)
+    return start + off
+
+
+class SidecarReader:
+    """Header of a side-car file and the means to turn byte ranges of its payload into list entries."""
+
+    def __init__(self, path):
+        self.path = path
+        with open(path, "rb") as f:
+            if f.read(len(SIDECAR_MAGIC)) != SIDECAR_MAGIC:
+                raise ValueError("%s is not a packed side-car" % path)
+            (n,) = struct.unpack("<Q", f.read(8))
+            if n > 64 << 20:
+                raise ValueError("%s: header of %d bytes" % (path, n))
+            self.header = json.loads(f.read(n).decode())
+        if self.header.get("version") != 1:
+            raise ValueError("%s: side-car version %r" % (path, self.header.get("version")))
+        self.start = (len(SIDECAR_MAGIC) + 8 + n + 4095) // 4096 * 4096
+        self.entries = self.header["entries"]
+        if os.path.getsize(path) < self.start + self.header["payload_bytes"]:
+            raise ValueError("%s is truncated" % path)
+
+    def matches(self, pkl_path, role, heads, compute, T=None):
+        """Made from this very pickle (name, size, mtime), for this role, head count and arithmetic: the mode of
+        every key/value image must be the one a fresh pack would choose now."""
+        from . import ops
+        from .attention import resolve_injected_compute
+        h = self.header
+        if h.get("role") != role or h.get("heads") != heads or h.get("compute") != compute:
+            return False
+        if pkl_path is not None and os.path.exists(pkl_path) and h.get("source") != _source_stamp(pkl_path):
+            return False
+        for e in self.entries:
+            temp = T if T is not None else (e.get("config") or {}).get("T", 1.0)
+            for item in e["items"].values():
+                if item["kind"] == "kv":
+                    want = ops._compute_code(resolve_injected_compute(compute, item["N"], item["d"], temp, item["d"] ** -0.5))
+                    if item["compute"] != want:
+                        return False
+        return True
+
+    def entry_range(self, i):
+        """(file offset, bytes) of entry i's contiguous payload range."""
+        e = self.entries[i]
+        return self.start + e["begin"], e["end"] - e["begin"]
+
+    def build_entry(self, i, flat):
+        """Entry i as a dict over `flat`, a uint8 tensor holding the entry's payload range."""
+        from . import ops
+        e = self.entries[i]
+        out = {"config": dict(e["config"])} if e.get("config") is not None else {}
+        for k, item in e["items"].items():
+            if item["kind"] == "same":
+                continue
+            raw = flat[item["offset"] - e["begin"]: item["offset"] - e["begin"] + item["nbytes"]]
+            if item["kind"] == "kv":
+                out[k] = ops.PackedKV(raw, item["B"], item["H"], item["N"], item["d"], item["compute"])
+            else:
+                out[k] = raw.view(_TORCH_DTYPES[item["dtype"]]).view(item["shape"])
+        for k, item in e["items"].items():
+            if item["kind"] == "same":
+                out[k] = out[item["as"]]
+        return out

@@ -16,6 +16,8 @@ def feat_merge_2sty(opt, cnt_feats, sty_feats_1, sty_feats_2, start_step=0):
       K ending in 'k' / 'v'  -> out[K] = char;     out[K+'_cnt'] = content; out[K+'_sty2'] = back
     Tensors are referenced, never copied.  Every step dict carries
     'config' = {'gamma', 'T', 'timestep': i, 'cnt_k': None, 'sty_q': None}.
+    A style list that holds no queries (a packed side-car keeps only what the attention reads: nothing
+    downstream reads '..._q_sty1' / '..._q_sty2') simply yields no such entries.
     """
     merged = [{'config': {'gamma': opt.gamma, 'T': opt.T, 'timestep': i, 'cnt_k': None, 'sty_q': None}}
               for i in range(NUM_STEPS)]
@@ -29,12 +31,35 @@ def feat_merge_2sty(opt, cnt_feats, sty_feats_1, sty_feats_2, start_step=0):
             is_kv = key.endswith('k') or key.endswith('v')
             if is_q:
                 step[key] = cnt[key]
-                step[key + '_sty1'] = sty1[key]
+                if key in sty1:
+                    step[key + '_sty1'] = sty1[key]
             if is_kv:
                 step[key] = sty1[key]
                 step[key + '_cnt'] = cnt[key]
-            if is_q or is_kv:
+            if is_kv or (is_q and key in sty2):
                 step[key + '_sty2'] = sty2[key]
+    return merged
+
+
+def feat_merge(opt, cnt_feats, sty_feats, start_step=0):
+    """The single-style merge (hf_run.py:40-68), for every step i >= 50 - start_step and every key K of the
+    style dict:  K ending in 'q' -> out[K] = content, out[K+'_sty'] = style;  K ending in 'k' / 'v' ->
+    out[K] = style, out[K+'_cnt'] = content.  The attention then runs the no-mask branch
+    (ldm/modules/attention.py:569-579): blended query, style keys and values, temperature T."""
+    merged = [{'config': {'gamma': opt.gamma, 'T': opt.T, 'timestep': i, 'cnt_k': None, 'sty_q': None}}
+              for i in range(NUM_STEPS)]
+    for i in range(NUM_STEPS):
+        if i < (NUM_STEPS - start_step):
+            continue
+        cnt, sty = cnt_feats[i], sty_feats[i]
+        step = merged[i]
+        for key in sty.keys():
+            if key[-1] == 'q':
+                step[key] = cnt[key]
+                step[key + '_sty'] = sty[key]
+            if key[-1] == 'k' or key[-1] == 'v':
+                step[key] = sty[key]
+                step[key + '_cnt'] = cnt[key]
     return merged
 
 

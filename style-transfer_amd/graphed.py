@@ -78,7 +78,9 @@ class GraphedUNet:
                 self.unet(self.x, self.t, self.ctx, injected_features=self.slots)
         torch.cuda.synchronize(x.device)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, stream=self.stream), torch.no_grad():
+        # thread_local: the feature loader's worker thread keeps reading, allocating and packing the next
+        # triple while this thread captures (in the default global mode its runtime calls invalidate the capture)
+        with torch.cuda.graph(self._graph, stream=self.stream, capture_error_mode="thread_local"), torch.no_grad():
             self.out = self.unet(self.x, self.t, self.ctx, injected_features=self.slots)
 
     def __call__(self, x, timesteps=None, context=None, injected_features=None):

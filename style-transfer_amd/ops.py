@@ -1,5 +1,10 @@
 """Tensor-level entry points: torch device tensors in, HIP kernels enqueued on the current stream.
 
+`compute` defaults to "f16" (SID_COMPUTE_F16QK: half-precision query/key operands, bf16 probabilities and
+values), the arithmetic that holds the path's 2e-2 bar at feature-sized logits; "bf16" and "fp32" select
+the other two.  The long-sequence kernels refuse "f16" for logit scales outside [2^-10, 2^10] / log2(e)
+(SID_EINVAL); style_transfer_amd.attention.resolve_compute picks "bf16" for such calls.
+
 PyTorch is used for device memory and streams only; all arithmetic of the path happens in
 libsid.so.  Every function raises if the library is missing or rejects the call.
 """
@@ -66,7 +71,7 @@ def _need_cuda(*ts):
 
 
 def injected_attention(x_q, q_cnt, k1, v1, k2, v2, k_cnt, v_cnt, mask_signed, gamma, T, scale,
-                       heads, q_self_coef=0.5, compute="bf16", out=None, flags=0, static_scratch=False):
+                       heads, q_self_coef=0.5, compute="f16", out=None, flags=0, static_scratch=False):
     """x_q (B,N,H*d); q_cnt,k*,v* (B*H,N,d); mask_signed (B,N) or (N,) float32 -> (B,N,H*d).
     static_scratch=True goes through sid_injected_attn_fwd_static (pass `out` to keep the call free of
     allocations altogether); calls on one GPU must then not overlap."""
@@ -113,13 +118,18 @@ FLAG_THROUGHPUT = 2      # SID_FLAG_THROUGHPUT: the caller keeps the GPU busy wi
 FLAG_BLOCK_SKIP = 1      # SID_FLAG_BLOCK_SKIP: drop key blocks whose softmax mass is provably nil
 
 
-def skip_counts(x_q, heads, compute="bf16", flags=FLAG_BLOCK_SKIP, packed=False):
+def skip_counts(x_q, heads, compute="f16", flags=FLAG_BLOCK_SKIP, packed=False, T=None, scale=None):
     """The block-skipping counters of the last injected-attention call made on the current stream with this
     shape, mode, flags and entry point: (query groups with a dead style block, content segments reduced to
     their logits, of those redone in full, query groups), or None where the flag has no effect (then the
-    call ran as if it were not set).  Synchronises."""
+    call ran as if it were not set).  Pass the call's T and scale: the library ignores the flag for
+    non-positive or vanishing logit scales, and the counters of such a call are not written.  Synchronises."""
     L = _lib.load()
     B, N, C = x_q.shape
+    if T is not None and scale is not None:
+        log2e = 1.4426950408889634
+        if not (T > 0 and scale > 0 and T * scale * log2e >= 2.0 ** -30 and scale * log2e >= 2.0 ** -30):
+            return None
     off = L.sid_injected_attn_skip_counts_offset(B, heads, N, C // heads, _compute_code(compute), int(flags), int(packed))
     if off < 0:
         return None
@@ -146,7 +156,7 @@ class PackedKV:
         return self.image.numel()
 
 
-def pack_kv(k, v, heads, compute="bf16"):
+def pack_kv(k, v, heads, compute="f16"):
     """k, v (B*H, N, d) float32 / bfloat16 -> PackedKV (one launch on the current stream)."""
     L = _lib.load()
     dev = _need_cuda(k, v)
@@ -291,7 +301,7 @@ def injected_attention_cached(x_q, q_cnt, kv1, kv2, partial, mask_signed, gamma,
     return out
 
 
-def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="bf16", out=None, flags=0):
+def plain_attention(q, k, v, logit_scale, heads, q_layout="bnhd", kv_layout="bnhd", compute="f16", out=None, flags=0):
     """softmax((q k^T) * logit_scale) v.  Layout 'bnhd': (B,N,H*d); 'bhnd': (B*H,N,d).
     Returns (B, Nq, H*d)."""
     L = _lib.load()

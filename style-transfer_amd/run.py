@@ -6,7 +6,11 @@
 For every `cnt char back` line of `<data_root>/dataset.txt` it does what run_ori.py:155-246 does
 between loading the features and decoding the image: reads the three feature files of the triple,
 builds the masked AdaIN initial latent, merges the features, and runs the 49 injected UNet
-evaluations under DDIM.  What it leaves to the host application is everything outside the path:
+evaluations under DDIM.  A two-column line `cnt sty` is the single-style path of the reference's
+hf_run.py:383-455 (initial latent adain(cnt, sty), `feat_merge`, the no-mask attention branch; the
+content image must have no mask file, as there).  The feature files of the next line are read, moved
+to HBM and packed while the current one samples, and every list stays resident under an LRU bound, so
+a sweep reads each file once (style_transfer_amd.loader).  What it leaves to the host application is everything outside the path:
 the VAE (the result is saved as the final latent `<cnt>_<char>_<back>.pt`, not a PNG), the CLIP text
 encoder (the unconditional embedding is read from `--uc`, a (1,77,768) tensor file, or is zeros),
 and DDIM inversion from images (feature files must exist; `style_transfer_amd.sampler.
@@ -53,9 +57,10 @@ def build_parser():
     p.add_argument('--uc', type=str, default='', help="file with the (1,77,768) unconditional text embedding; zeros if empty")
     p.add_argument('--unet_config', type=str, default='', help="JSON with UNetModel keyword arguments (default: SD-v1)")
     p.add_argument('--random_unet', action='store_true', help="seeded random weights instead of --ckpt (measurement)")
-    p.add_argument('--compute', default='bf16', choices=['bf16', 'f16', 'fp32'],
-                   help="attention kernel arithmetic: bf16 operands; f16 = half-precision query/key operands in the injected "
-                        "layers (same speed, finer logits); fp32 = split-bf16, f32-grade")
+    p.add_argument('--compute', default='f16', choices=['bf16', 'f16', 'fp32'],
+                   help="attention kernel arithmetic: f16 (default) = half-precision query/key operands, bf16 probabilities and "
+                        "values (2e-2 of the fp32 reference also at feature-sized logits); bf16 = bf16 operands throughout "
+                        "(3 %% faster on the longest layers, up to 3.2e-2 at feature-sized logits); fp32 = split-bf16, f32-grade")
     p.add_argument('--feature_dtype', default='float32', choices=['float32', 'bfloat16'], help="storage type of the feature store in HBM")
     p.add_argument('--graph_unet', action='store_true', help="replay every UNet evaluation as one HIP graph (not with a residual file)")
     p.add_argument('--block_skip', action='store_true',
@@ -66,25 +71,41 @@ def build_parser():
                         "loaded) and reuse it, its feature list and its filtered residuals for every style pair with the "
                         "same content image: the dataset.txt lines of one content are processed next to each other, on one rank")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
+    p.add_argument('--no_prefetch', action='store_true', help="read the feature files of a line only when its turn comes (the reference's order)")
+    p.add_argument('--sidecar', default='use', choices=['off', 'use', 'write'],
+                   help="packed side-car files beside the pickles ({base}_cnt.sidpack / {base}_sty.sidpack): 'use' reads one when it "
+                        "is present and was made from the pickle beside it, 'write' also writes one after packing a pickle")
+    p.add_argument('--store_cache_gb', type=float, default=96.0, help="HBM the loaded feature lists may occupy before the least "
+                                                                      "recently used one is dropped")
     return p
 
 
 def list_triples(data_root, dataset_txt="dataset.txt"):
     """(cnt_path, char_path, back_path) per non-empty line; FileNotFoundError for a missing image, with
-    the reference's messages (dataset.py:17-37)."""
+    the reference's messages (dataset.py:17-37).  A line of two names, `cnt sty`, is a single-style pair:
+    (cnt_path, sty_path, None), the style image looked up under sty/char, then sty."""
     triples = []
     with open(os.path.join(data_root, dataset_txt)) as f:
         for line in f:
             line = line.strip()
             if not line:
                 continue
-            cnt, char, back = line.split()
-            paths = (os.path.join(data_root, "cnt", cnt), os.path.join(data_root, "sty/char", char),
-                     os.path.join(data_root, "sty/back", back))
-            for what, pth in zip(("Content", "Char", "Back"), paths):
+            names = line.split()
+            if len(names) == 2:
+                cnt, sty = names
+                sty_path = os.path.join(data_root, "sty/char", sty)
+                if not os.path.isfile(sty_path):
+                    sty_path = os.path.join(data_root, "sty", sty)
+                found = ((("Content", os.path.join(data_root, "cnt", cnt)), ("Style", sty_path)))
+            else:
+                cnt, char, back = names
+                found = (("Content", os.path.join(data_root, "cnt", cnt)), ("Char", os.path.join(data_root, "sty/char", char)),
+                         ("Back", os.path.join(data_root, "sty/back", back)))
+            for what, pth in found:
                 if not os.path.isfile(pth):
                     raise FileNotFoundError("%s image not found: %s" % (what, pth))
-            triples.append(paths)
+            paths = tuple(p for _, p in found)
+            triples.append(paths if len(paths) == 3 else paths + (None,))
     return triples
 
 
@@ -109,12 +130,46 @@ def load_unet(opt, device):
     return model.eval().to(device)
 
 
-def stylise(opt, model, sampler, triple, uc, device):
-    """One triple -> final latent (1, C, H/f, W/f)."""
-    from . import feature_store as fs
-    from .features import masked_adain_init
-    from .high_frequency import make_content_injection_schedule, patch_decoder_resblocks_h_and_cnt_hf
+def model_heads(model):
+    mods = model.attention_modules()
+    return mods[0].heads if mods else 8
+
+
+def make_loader(opt, model, device, prefetch=None):
+    """The feature-store loader of a run: packs for the model's head count and the run's arithmetic."""
+    from .loader import FeatureLoader
+    dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
+    packed = not opt.unpacked_store and not opt.without_attn_injection
+    return FeatureLoader(opt.precomputed, device, heads=model_heads(model), compute=opt.compute, T=opt.T, dtype=dtype,
+                         packed=packed, cache_content=packed and getattr(opt, "cache_content", False),
+                         cache_bytes=int(getattr(opt, "store_cache_gb", 96.0) * (1 << 30)),
+                         sidecar=getattr(opt, "sidecar", "use"),
+                         prefetch=(not getattr(opt, "no_prefetch", False)) if prefetch is None else prefetch)
+
+
+def bases_of(opt, triple):
+    """File stems of a line's feature files.  A three-name line whose content image has no mask file cannot
+    take the two-style path (the reference's run_ori.py:228 fails on the missing file): it is stylised with
+    its character style alone, as a two-name line."""
     cnt_path, char_path, back_path = triple
+    mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")
+    if back_path is not None and not os.path.isfile(mask_file):
+        print("no mask file %s: %s is stylised with the single style %s" % (mask_file, base(cnt_path), base(char_path)))
+        back_path = None
+    if back_path is None and os.path.isfile(mask_file):
+        raise ValueError("%s has a mask file: the mask-based attention needs a character and a background style "
+                         "(three names per line); the single-style path is for content images without a mask "
+                         "(hf_run.py:383-455)" % base(cnt_path))
+    return (base(cnt_path), base(char_path), base(back_path) if back_path is not None else None)
+
+
+def stylise(opt, model, sampler, triple, uc, device, store=None):
+    """One triple -> final latent (1, C, H/f, W/f).  `store`: its FeatureStore from a FeatureLoader (default:
+    loaded here, synchronously)."""
+    from . import feature_store as fs
+    from .features import adain, masked_adain_init
+    from .high_frequency import make_content_injection_schedule, patch_decoder_resblocks_h_and_cnt_hf
+    cnt_path = triple[0]
     model.set_content_name(cnt_path)                                   # run_ori.py:159-161
     if getattr(opt, "block_skip", False):
         from . import ops
@@ -123,23 +178,19 @@ def stylise(opt, model, sampler, triple, uc, device):
             if isinstance(m, CrossAttention):
                 m.kernel_flags |= ops.FLAG_BLOCK_SKIP      # kept per layer only where blocks actually die
                 m.skip_policy = "auto"
-    dtype = torch.bfloat16 if opt.feature_dtype == "bfloat16" else None
-    mask_file = os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")
-    packed = not opt.unpacked_store and not opt.without_attn_injection and os.path.isfile(mask_file)
-    cache_content = packed and getattr(opt, "cache_content", False)
-    kept = getattr(sampler, "_content_kept", None)          # (content name, its feature list) of the previous triple
-    cnt_list = kept[1] if cache_content and kept is not None and kept[0] == base(cnt_path) else None
-    store = fs.FeatureStore.load(opt.precomputed, base(cnt_path), base(char_path), base(back_path), device, dtype, cnt=cnt_list)
-    if packed:
-        store.pack(compute=opt.compute, cache_content=cache_content)   # pre-packed K/V serve the mask-based injected attention
-        # (every injected layer of SD-v1 has head_dim 40 or 80, which the f16 mode serves)
-    sampler._content_kept = (base(cnt_path), store.cnt) if cache_content else None
-    cnt_z, char_z, back_z = store.z_enc()
-    if opt.without_init_adain:
-        x_T = cnt_z
+    if store is None:
+        loader = make_loader(opt, model, device, prefetch=False)
+        store = loader.get(bases_of(opt, triple))
+    if store.back is None:                                             # single style: hf_run.py:424-428
+        cnt_z, sty_z = store.z_enc()
+        x_T = cnt_z if opt.without_init_adain else adain(cnt_z, sty_z)
     else:
-        mask = np.load(os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")).astype(np.float32)
-        x_T = masked_adain_init(cnt_z, char_z, back_z, torch.from_numpy(mask).to(device))
+        cnt_z, char_z, back_z = store.z_enc()
+        if opt.without_init_adain:
+            x_T = cnt_z
+        else:
+            mask = np.load(os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")).astype(np.float32)
+            x_T = masked_adain_init(cnt_z, char_z, back_z, torch.from_numpy(mask).to(device))
     feats = None if opt.without_attn_injection else store.merged(opt, start_step=opt.start_step)
     res_path = os.path.join(opt.precomputed, base(cnt_path) + "_residuals_all.pkl")
     callback = None
@@ -217,12 +268,22 @@ def main(argv=None):
     mine = lists[rank]
     begin = time.time()
     latents = []
+    loader = make_loader(opt, model, device)
+    keys = [bases_of(opt, triples[idx]) for idx in mine]
+    if keys:
+        loader.request(keys[0])
     with torch.no_grad():
-        for idx in mine:
-            z = stylise(opt, model, sampler, triples[idx], uc, device)
+        for j, idx in enumerate(mine):
+            store = loader.get(keys[j])
+            if j + 1 < len(mine):
+                loader.request(keys[j + 1])                # read, upload and pack while this one samples
+            z = stylise(opt, model, sampler, triples[idx], uc, device, store)
             latents.append(z[0].float())
-            name = "%s_%s_%s.pt" % tuple(base(p) for p in triples[idx])
+            name = "_".join(base(p) for p in triples[idx] if p is not None) + ".pt"
             torch.save(z.cpu(), os.path.join(opt.output_path, name))  # run_ori.py:245 names the PNG the same way
+            del store
+    loader.close()
+    opt.loader_stats = dict(loader.stats)
     shape = (opt.C, opt.H // opt.f, opt.W // opt.f)
     local_stack = torch.stack(latents) if latents else torch.zeros((0,) + shape, device=device)
     local_stack, _ = sharding.pad_to_common(local_stack, len(triples), world, per=max(len(l) for l in lists))
@@ -232,7 +293,9 @@ def main(argv=None):
     if rank == 0:
         allz = sharding.reassemble_lists(gathered, lists)
         torch.save(allz.cpu(), os.path.join(opt.output_path, "latents_all.pt"))
-        print("Total end: %.3f s for %d triples on %d GPU(s)" % (time.time() - begin, len(triples), world))
+        st = loader.stats
+        print("Total end: %.3f s for %d triples on %d GPU(s); rank 0 read %d files (%.2f GB, %d from side-cars), %d served from HBM"
+              % (time.time() - begin, len(triples), world, st["files"], st["file_bytes"] / 1e9, st["routes"]["sidecar"], st["hits"]))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

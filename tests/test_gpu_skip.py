@@ -12,6 +12,11 @@ from style_transfer_amd import ops, synth
 
 pytestmark = pytest.mark.gpu
 H = 8
+# The tests run in the default arithmetic (half-precision logits operands), where the oracle bar of the path
+# (2e-2) holds at feature-sized logits too; with bf16 operands the operand rounding alone costs up to 3.2e-2
+# at three times unit scale, and only the explicitly-bf16 parametrisations take that bound.
+MODE = "f16"
+BAR = {"f16": 2e-2, "bf16": 3.5e-2}
 
 
 def inputs(seed, B, N, d, sigma, mask):
@@ -86,15 +91,15 @@ def test_dropped_blocks_weigh_nothing():
     the float64 mass of those blocks must be below half an ulp of f32 on every sampled row."""
     N, d = 4096, 40
     t = inputs(7050, 1, N, d, 3.0, "halves")
-    out = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
-    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    out = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE)
     assert dead == groups and redone == 0 and lo >= groups
     rows = (synth.hash_u64(7051, 64) % np.uint64(N)).astype(np.int64)
     mass = block_mass_rows(t, 0, rows, d)
     far = np.where(rows < N // 2, mass[..., 1], mass[..., 0])      # m = +1 on the first half: block 2 is the far one
     print("largest dropped mass: style %.2e, content %.2e" % (far.max(), mass[..., 2].max()))
     assert far.max() < 2.0 ** -25 and mass[..., 2].max() < 2.0 ** -25
-    assert rel_err(out[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+    assert rel_err(out[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < BAR[MODE]
 
 
 @pytest.mark.parametrize("compute", ["bf16", "f16"])
@@ -131,7 +136,7 @@ def test_flag_changes_nothing_that_matters(N, d, sigma, mask, compute, monkeypat
     rows = (synth.hash_u64(7001, 10) % np.uint64(N)).astype(np.int64)
     for b in (0, 1):
         ref = oracle_rows(t, b, rows, d)
-        assert rel_err(skipped[b].cpu().numpy()[rows], ref) < (3.5e-2 if compute == "bf16" else 1e-2)
+        assert rel_err(skipped[b].cpu().numpy()[rows], ref) < BAR[compute]
 
 
 def test_sampled_bounds_never_drop_a_block_that_matters():
@@ -143,14 +148,14 @@ def test_sampled_bounds_never_drop_a_block_that_matters():
     t = inputs(7100, 1, N, d, 3.0, "halves")
     t["k2"][:, 2001] *= 6.0
     t["k_cnt"][:, 3001] = t["q_cnt"][:, 100] * 4.0
-    plain = run(t, d, "bf16", 0)
-    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
-    counts = ops.skip_counts(t["xq"], H, "bf16")
+    plain = run(t, d, MODE, 0)
+    skipped = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    counts = ops.skip_counts(t["xq"], H, MODE)
     print("adversarial: counts", counts)
     assert counts[2] > 0                         # the towering content key was caught
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     rows = np.array([0, 100, 101, 255, 2047, 2048, 4095])
-    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < BAR[MODE]
 
 
 def test_flag_is_ignored_where_it_cannot_apply():
@@ -160,20 +165,20 @@ def test_flag_is_ignored_where_it_cannot_apply():
         b = run(t, d, compute, ops.FLAG_BLOCK_SKIP, T=T)
         assert torch.equal(a, b), (N, d, compute, T)
     assert ops.skip_counts(t["xq"], H, "fp32") is None
-    assert ops.skip_counts(torch.empty(1, 1024, 640, device="cuda:0"), H, "bf16") is None
+    assert ops.skip_counts(torch.empty(1, 1024, 640, device="cuda:0"), H, MODE) is None
 
 
 def test_packed_entry_point_takes_the_flag():
     N, d = 4096, 40
     t = inputs(7300, 1, N, d, 3.0, "disc")
-    kv = [ops.pack_kv(t[k], t[v], H, "bf16") for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    kv = [ops.pack_kv(t[k], t[v], H, MODE) for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
     plain = ops.injected_attention_packed(t["xq"], t["q_cnt"], *kv, t["mask"], 0.5, 1.5, d ** -0.5, H)
     skipped = ops.injected_attention_packed(t["xq"], t["q_cnt"], *kv, t["mask"], 0.5, 1.5, d ** -0.5, H,
                                             flags=ops.FLAG_BLOCK_SKIP)
-    counts = ops.skip_counts(t["xq"], H, "bf16", packed=True)
+    counts = ops.skip_counts(t["xq"], H, MODE, packed=True)
     assert counts[0] > 0
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
-    unpacked = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    unpacked = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
     assert torch.equal(unpacked, skipped)
 
 
@@ -181,14 +186,14 @@ def test_packed_entry_point_takes_the_flag():
 def test_other_kernel_instances(N, d):
     """Head dims whose instances stage one key tile per stage or hold a shorter key-only ring."""
     t = inputs(7400 + d, 1, N, d, 3.0, "disc")
-    plain = run(t, d, "bf16", 0)
-    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
-    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    plain = run(t, d, MODE, 0)
+    skipped = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE)
     print("N=%d d=%d: counts %s" % (N, d, (dead, lo, redone, groups)))
     assert dead == groups and lo > 0
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     rows = (synth.hash_u64(7401, 8) % np.uint64(N)).astype(np.int64)
-    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < 3.5e-2
+    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < BAR[MODE]
 
 
 def test_images_with_different_masks_and_bf16_storage():
@@ -197,14 +202,14 @@ def test_images_with_different_masks_and_bf16_storage():
     t = inputs(7500, 3, N, d, 3.0, "disc")
     t["mask"][1] = 1.0                        # one side only: a single run of groups, no padding between sides
     t["mask"][2] = -t["mask"][2]
-    plain = run(t, d, "bf16", 0)
-    skipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
-    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16")
+    plain = run(t, d, MODE, 0)
+    skipped = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE)
     assert groups == H * (9 + 8 + 9) and dead == groups
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     tb = {k: (v.to(torch.bfloat16) if k != "mask" else v) for k, v in t.items()}
-    plain_b = run(tb, d, "bf16", 0)
-    skipped_b = run(tb, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    plain_b = run(tb, d, MODE, 0)
+    skipped_b = run(tb, d, MODE, ops.FLAG_BLOCK_SKIP)
     assert skipped_b.dtype == torch.bfloat16
     assert (plain_b.float() - skipped_b.float()).abs().max().item() <= 2 * SAME_BAND * plain.abs().max().item()
 
@@ -212,16 +217,16 @@ def test_images_with_different_masks_and_bf16_storage():
 def test_static_scratch_and_graph_replay_with_the_flag():
     N, d = 4096, 40
     t = inputs(7600, 1, N, d, 3.0, "disc")
-    eager = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP).clone()
+    eager = run(t, d, MODE, ops.FLAG_BLOCK_SKIP).clone()
     out = torch.empty_like(eager)
     static = ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"], t["mask"],
-                                    0.5, 1.5, d ** -0.5, H, compute="bf16", out=out, flags=ops.FLAG_BLOCK_SKIP,
+                                    0.5, 1.5, d ** -0.5, H, compute=MODE, out=out, flags=ops.FLAG_BLOCK_SKIP,
                                     static_scratch=True)
     assert torch.equal(static, eager)
     st = torch.cuda.Stream()
     gout = torch.empty_like(eager)
     call = lambda: ops.injected_attention(t["xq"], t["q_cnt"], t["k1"], t["v1"], t["k2"], t["v2"], t["k_cnt"], t["v_cnt"],
-                                          t["mask"], 0.5, 1.5, d ** -0.5, H, compute="bf16", out=gout,
+                                          t["mask"], 0.5, 1.5, d ** -0.5, H, compute=MODE, out=gout,
                                           flags=ops.FLAG_BLOCK_SKIP)
     with torch.cuda.stream(st):
         call()
@@ -233,7 +238,7 @@ def test_static_scratch_and_graph_replay_with_the_flag():
     t["mask"].neg_()                          # the regrouping is part of the graph: a new mask is picked up
     graph.replay()
     torch.cuda.synchronize()
-    flipped = run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    flipped = run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
     assert torch.equal(gout, flipped)
 
 
@@ -257,7 +262,7 @@ def test_random_shapes_and_masks():
             m[b, soft] *= 0.1
             m[b, int(rng.integers(0, N))] = 0.0
         t["mask"] = m.contiguous()
-        compute = "f16" if (33 <= d <= 48 or 65 <= d <= 80) and case % 2 else "bf16"
+        compute = "f16" if case % 2 else "bf16"
         plain = run(t, d, compute, 0)
         skipped = run(t, d, compute, ops.FLAG_BLOCK_SKIP)
         dead, lo, redone, groups = ops.skip_counts(t["xq"], H, compute)
@@ -275,13 +280,13 @@ def test_with_the_throughput_decomposition():
     N, d = 4096, 40
     t = inputs(7800, 2, N, d, 3.0, "disc")
     both = ops.FLAG_BLOCK_SKIP | ops.FLAG_THROUGHPUT
-    plain = run(t, d, "bf16", ops.FLAG_THROUGHPUT)
-    skipped = run(t, d, "bf16", both)
-    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, "bf16", flags=both)
+    plain = run(t, d, MODE, ops.FLAG_THROUGHPUT)
+    skipped = run(t, d, MODE, both)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE, flags=both)
     assert dead == groups and groups == 2 * H * 9 and lo > 0 and redone <= lo
     assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
     rows = (synth.hash_u64(7801, 8) % np.uint64(N)).astype(np.int64)
-    assert rel_err(skipped[1].cpu().numpy()[rows], oracle_rows(t, 1, rows, d)) < 3.5e-2
+    assert rel_err(skipped[1].cpu().numpy()[rows], oracle_rows(t, 1, rows, d)) < BAR[MODE]
 
 
 @pytest.mark.parametrize("B", [1, 2])
@@ -301,13 +306,13 @@ def test_token_regrouping_matches_a_stable_partition(B):
     if B > 1:
         m[1, :] = 1.0                                       # a single side
     t["mask"] = torch.from_numpy(m).to("cuda:0")
-    run(t, d, "bf16", ops.FLAG_BLOCK_SKIP)
+    run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
     torch.cuda.synchronize()
     L = lib.load()
-    off = L.sid_injected_attn_skip_counts_offset(B, H, N, d, lib.COMPUTE_BF16, 1, 0)
+    off = L.sid_injected_attn_skip_counts_offset(B, H, N, d, ops._compute_code(MODE), 1, 0)
     ws = ops._workspaces[(0, torch.cuda.current_stream().cuda_stream)]
     plan = (ctypes.c_int * 40)()
-    assert L.sid_attn_plan(3, B, H, N, N, d, lib.COMPUTE_BF16, 1, plan) == 0
+    assert L.sid_attn_plan(3, B, H, N, N, d, ops._compute_code(MODE), 1, plan) == 0
     own_middle = B * H * (plan[6] + 2) * plan[0] <= 256 * (1 if plan[4] == 8 else 2)
     assert own_middle == (B == 1)
     GR, groups_max = 512, N // 512 + 2
@@ -349,6 +354,6 @@ def test_auto_policy_keeps_the_flag_only_where_blocks_die(sigma, kept, tmp_path)
         first = attn(t["xq"], **kw)
         assert attn.skip_policy == "fixed" and bool(attn.kernel_flags & ops.FLAG_BLOCK_SKIP) == kept
         second = attn(t["xq"], **kw)
-    ref = run(t, d, "bf16", 0)
+    ref = run(t, d, MODE, 0)
     for out in (first, second):
         assert (out - ref).abs().max().item() <= SAME_BAND * ref.abs().max().item()

@@ -18,7 +18,7 @@ def _inputs(dev, seed, H, N, d):
     return g, m
 
 
-def _both(g, m, H, d, gamma, T, compute="bf16"):
+def _both(g, m, H, d, gamma, T, compute="f16"):
     args = (g["xq"], g["q_cnt"], g["k1"], g["v1"], g["k2"], g["v2"], g["k_cnt"], g["v_cnt"], m, gamma, T, d ** -0.5, H)
     want = ops.injected_attention(*args, compute=compute)
     out = torch.full_like(want, float("nan"))
@@ -43,7 +43,7 @@ def test_static_scratch_two_calls_second_smaller():
     assert torch.equal(got, want)
     got, want = _both(big, mb, H, 40, 0.5, 1.5)         # and the large one again
     assert torch.equal(got, want)
-    # the oracle's bar as well (2e-2 relative with bf16 operands), on sampled rows of the small call
+    # the oracle's bar as well (2e-2 relative), on the small call
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import sid_oracle as orc
@@ -67,3 +67,29 @@ def test_static_scratch_rejects_oversize():
     with pytest.raises(lib.SidError) as e:
         ops.injected_attention(x, f, f, f, f, f, f, f, m, 0.5, 1.5, d ** -0.5, H, out=torch.empty_like(x), static_scratch=True)
     assert e.value.code == -12 and "static" in str(e.value)
+
+
+def test_static_scratch_under_graph_capture_allocates_nothing():
+    """What the entry point is for: after one eager call on the device (it looks the array's address up),
+    a call is captured into a HIP graph with a caller-provided output, so nothing may allocate: the
+    caching allocator's counters do not move during capture, and the replay equals the eager result."""
+    dev = torch.device("cuda:0")
+    H, N, d = 8, 1024, 80
+    g, m = _inputs(dev, 904, H, N, d)
+    args = (g["xq"], g["q_cnt"], g["k1"], g["v1"], g["k2"], g["v2"], g["k_cnt"], g["v_cnt"], m, 0.75, 1.5, d ** -0.5, H)
+    out = torch.empty_like(g["xq"])
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        eager = ops.injected_attention(*args, out=out, static_scratch=True).clone()      # first call: eager
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    count = lambda: torch.cuda.memory_stats(dev)["allocation.all.allocated"]
+    with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+        before = count()             # (entering the capture allocates the graph's own bookkeeping tensors)
+        ops.injected_attention(*args, out=out, static_scratch=True)
+        after = count()
+    assert after == before
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
