@@ -166,13 +166,13 @@ class FeatureLoader:
                         fs.pack_feature_list(feats, self.heads, self.compute, self.T)
                     if want_packed and role == "cnt" and self.cache_content:
                         fs.cache_content_blocks(feats, self.heads)
-                    blocks = self._live_blocks(feats)
                     event = torch.cuda.Event()
                     event.record(self._stream)
                 if want_packed and route == "pkl" and self.sidecar == "write":
                     self._stream.synchronize()
                     fs.write_sidecar(side, feats, role, self.heads, self.compute, pkl)
-            hbm = sum(b.numel() * b.element_size() for b in blocks) if blocks else 0
+            blocks = self._live_blocks(feats)
+            hbm = sum(b.untyped_storage().nbytes() for b in blocks)
         return _Loaded(feats, blocks or [], event, hbm, nfile, time.perf_counter() - t0, route)
 
     @staticmethod

@@ -116,9 +116,10 @@ def base(path):
 def load_unet(opt, device):
     from . import unet as U
     cfg = json.load(open(opt.unet_config)) if opt.unet_config else {}
+    if opt.random_unet:
+        torch.manual_seed(opt.seed)             # before construction: the constructor draws the biases
     model = U.UNetModel(**cfg)
     if opt.random_unet:
-        torch.manual_seed(opt.seed)
         for p in model.parameters():
             if p.dim() > 1:
                 torch.nn.init.normal_(p, std=p[0].numel() ** -0.5)

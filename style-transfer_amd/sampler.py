@@ -33,10 +33,11 @@ class DDIMSampler:
 
     @torch.no_grad()
     def sample(self, x_T, unconditional_conditioning, injected_features=None, start_step=9999, callback=None,
-               generator=None):
+               generator=None, img_callback=None):
         """x_T (B,4,h,w) -> final latent.  `injected_features`: list indexed by loop position i
         (i = 0 is the largest timestep), as feat_merge_2sty produces; `callback(i)` runs after step i
-        (the high-frequency patch reads the timestep it sets)."""
+        (the high-frequency patch reads the timestep it sets), then `img_callback(pred_x0, img, step)`
+        (ldm/models/diffusion/ddim.py:230-233)."""
         img = x_T
         b = x_T.shape[0]
         total = len(self.ddim_timesteps)
@@ -56,6 +57,8 @@ class DDIMSampler:
                 img = img + sigma_t * torch.randn(img.shape, device=img.device, generator=generator)
             if callback is not None:
                 callback(i)
+            if img_callback is not None:
+                img_callback(pred_x0, img, int(step))
         return img
 
     @torch.no_grad()

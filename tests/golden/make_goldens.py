@@ -275,6 +275,14 @@ def gen_feat_merge():
     with open(os.path.join(HERE, "feat_merge.json"), "w") as f:
         json.dump(out, f)
     print("feat_merge: steps", {k: sum(len(d) > 1 for d in v) for k, v in out.items()})
+    # the single-style merge of hf_run.py:40-68, compiled the same way
+    src = open(os.path.join(REF, "hf_run.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "feat_merge"][0]
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "hf_run.py", "exec"), ns)
+    single = {str(ss): ns["feat_merge"](opt, mk("cnt"), mk("sty"), start_step=ss) for ss in (49, 30, 50, 0)}
+    with open(os.path.join(HERE, "feat_merge_single.json"), "w") as f:
+        json.dump(single, f)
 
 
 def gen_adain():
@@ -585,8 +593,121 @@ def gen_ddim():
     print("ddim: tables", sum(k.startswith("tab/") for k in out), "trajectories", sum(k.startswith("encode/") for k in out))
 
 
+def gen_loop():
+    """The whole stylisation loop of run_ori.py:224-242 run with the REFERENCE's own pieces: its UNetModel
+    (half width, name-seeded weights) as `apply_model` under its DDIMSampler.sample for all 49 evaluations
+    of a 50-step schedule (start_step 49), features merged by its feat_merge_2sty, the initial latent from
+    its adain and the mask blend of run_ori.py:228-232, a real mask file on every attention module.
+    Features: for every loop position i the q, k, v of output blocks 6-11 captured in gen_pkl mode
+    (generate_pkl_only.py:113-142) from one forward of the seeded content / character / background latent at
+    that position's timestep, so that the test can regenerate them with its own network one forward at a
+    time.  Pinned: the final latent, the latents after 16 and 32 evaluations, checksums of the features."""
+    import ast
+    import contextlib
+    import io
+    import types
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    model = build_ref_unet()
+    attns = [m for m in model.modules() if isinstance(m, ref_attn.CrossAttention)]
+
+    class Wrapper:                       # LatentDiffusion as the sampler sees it (ddpm.py:117-146, :892-1006, :1430-1435)
+        def __init__(self):
+            betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.0120, cosine_s=8e-3)
+            ac = np.cumprod(1.0 - betas, axis=0)
+            f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+            self.betas, self.alphas_cumprod = f32(betas), f32(ac)
+            self.alphas_cumprod_prev = f32(np.append(1.0, ac[:-1]))
+            self.sqrt_alphas_cumprod = f32(np.sqrt(ac))
+            self.sqrt_one_minus_alphas_cumprod = f32(np.sqrt(1.0 - ac))
+            self.num_timesteps = 1000
+            self.device = torch.device("cpu")
+            self.parameterization = "eps"
+
+        def apply_model(self, x, t, c, injected_features=None):
+            return model(x, t, context=c, injected_features=injected_features)
+
+    class Sampler(DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    sampler = Sampler(Wrapper())
+    with quiet:
+        sampler.make_schedule(ddim_num_steps=50, ddim_eta=0.0, verbose=False)
+    time_range = np.flip(sampler.ddim_timesteps)
+
+    def capture(tag, t_int):
+        for m in attns:
+            m.gen_pkl = True
+        x, ctx = unet_inputs(tag)
+        with torch.no_grad():
+            model(torch.from_numpy(x), torch.tensor([int(t_int)]), torch.from_numpy(ctx))
+        feats = {"config": {"T": 1.5}, "z_enc": torch.from_numpy(x)}
+        for bi in range(6, 12):
+            a = model.output_blocks[bi][1].transformer_blocks[0].attn1
+            for nm in "qkv":
+                feats[f"output_block_{bi}_self_attn_{nm}"] = getattr(a, nm).clone()
+        for m in attns:
+            m.gen_pkl = False
+        return feats
+
+    lists = {tag: [capture(tag, t) for t in time_range] for tag in ("cnt", "char", "back")}
+    out = {}
+    for tag, lst in lists.items():
+        for i in (1, 17, 49):
+            for k, v in lst[i].items():
+                if torch.is_tensor(v) and k != "z_enc":
+                    out[f"feat/{tag}/{i}/{k}"] = np.array([v.double().sum().item(), (v.double() ** 2).sum().item()])
+    src = open(os.path.join(REF, "run_ori.py")).read()
+    ns = {"torch": torch}
+    for name in ("feat_merge_2sty", "adain"):
+        fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "run_ori.py", "exec"), ns)
+    case = {"gamma": 0.75, "T": 1.5, "start_step": 49, "mask": MASK_NAMES[0], "steps": 50, "inter": [16, 32]}
+    opt = types.SimpleNamespace(gamma=case["gamma"], T=case["T"])
+    feat_maps = ns["feat_merge_2sty"](opt, lists["cnt"], lists["char"], lists["back"], start_step=case["start_step"])
+    mask_np = np.load(os.path.join(MASK_DIR, case["mask"] + ".npy"))
+    cnt_z, char_z, back_z = (torch.clone(lists[t][0]["z_enc"]) for t in ("cnt", "char", "back"))
+    mask = torch.tensor(mask_np, dtype=torch.float32).unsqueeze(0).unsqueeze(0)            # run_ori.py:228-232
+    mask = torch.nn.functional.interpolate(mask, size=(cnt_z.shape[2], cnt_z.shape[3]), mode="bilinear", align_corners=False)
+    mask = mask.expand(-1, cnt_z.shape[1], -1, -1)
+    x_T = mask * ns["adain"](cnt_z, char_z) + (1 - mask) * ns["adain"](cnt_z, back_z)
+    out["x_T"] = x_T.numpy()
+    _, ctx = unet_inputs("cur")
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "img_mask.npy"), mask_np)
+        for m in attns:
+            m.cnt_name = os.path.join(td, "img.jpg")
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            samples, inter = sampler.sample(S=50, batch_size=1, shape=[4, 16, 16], verbose=False,
+                                            unconditional_conditioning=torch.from_numpy(ctx), eta=0.0, x_T=x_T.clone(),
+                                            injected_features=feat_maps, start_step=case["start_step"], log_every_t=1)
+        # the same loop without injection (features None), to show that the pin is sensitive to the injection
+        for m in attns:
+            m.cnt_name = os.path.join(td, "nomask.jpg")
+        with quiet, contextlib.redirect_stderr(io.StringIO()):
+            plain, _ = sampler.sample(S=50, batch_size=1, shape=[4, 16, 16], verbose=False,
+                                      unconditional_conditioning=torch.from_numpy(ctx), eta=0.0, x_T=x_T.clone(),
+                                      start_step=case["start_step"])
+    xs = inter["x_inter"]                 # [x_T, after evaluation 1, 2, ...]
+    assert len(xs) == 1 + 49, len(xs)
+    out["final"] = samples.numpy()
+    for n in case["inter"]:
+        out[f"after/{n}"] = xs[n].numpy()
+    out["plain_final"] = plain.numpy()
+    np.savez_compressed(os.path.join(HERE, "loop.npz"), **out)
+    with open(os.path.join(HERE, "loop_case.json"), "w") as f:
+        json.dump(case, f)
+    rng = float(out["final"].max() - out["final"].min())
+    print("loop: final std %.3f range %.3f; injected vs plain max diff %.3f; finite %s"
+          % (out["final"].std(), rng, np.abs(out["final"] - out["plain_final"]).max(), np.isfinite(out["final"]).all()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain", "unet", "hf_patch", "ddim"]
+    which = sys.argv[1:] or ["masks", "hf", "attention", "feat_merge", "adain", "unet", "hf_patch", "ddim", "loop"]
+    if "loop" in which:
+        gen_loop()
     if "ddim" in which:
         gen_ddim()
     if "hf_patch" in which:

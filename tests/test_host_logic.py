@@ -231,3 +231,28 @@ def test_block_skip_planning_queries():
     assert L.sid_injected_attn_skip_counts_offset(1, 8, 4096, 40, lib.COMPUTE_F32X3, 1, 0) == -1      # f32-grade mode
     assert L.sid_injected_attn_skip_counts_offset(1, 8, 1024, 80, lib.COMPUTE_BF16, 1, 0) == -1        # short key blocks
     assert ws <= lib.STATIC_SCRATCH_BYTES
+
+
+def test_single_style_feat_merge_matches_reference():
+    """feat_merge of hf_run.py:40-68 (fixture generated by running that function itself)."""
+    from style_transfer_amd.features import feat_merge
+    with open(os.path.join(GOLDEN, "feat_merge_single.json")) as f:
+        gold = json.load(f)
+    keys = ["z_enc", "config"] + [f"output_block_{b}_self_attn_{t}" for b in range(6, 12) for t in "qkv"]
+    mk = lambda tag: [{k: f"{tag}[{i}].{k}" for k in keys} for i in range(50)]
+    opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+    for start_step, want in gold.items():
+        assert feat_merge(opt, mk("cnt"), mk("sty"), start_step=int(start_step)) == want, start_step
+
+
+def test_two_style_merge_tolerates_a_style_list_without_queries():
+    """A packed side-car of a style file keeps no queries: the merge then has no '_q_sty1' / '_q_sty2' entries
+    (nothing reads them) and every other key is as before."""
+    from style_transfer_amd.features import feat_merge_2sty
+    keys = ["z_enc", "config"] + [f"output_block_{b}_self_attn_{t}" for b in range(6, 12) for t in "qkv"]
+    mk = lambda tag, drop=False: [{k: f"{tag}[{i}].{k}" for k in keys if not (drop and k.endswith("_q"))} for i in range(50)]
+    opt = types.SimpleNamespace(gamma=0.75, T=1.5)
+    full = feat_merge_2sty(opt, mk("cnt"), mk("char"), mk("back"), start_step=49)
+    lean = feat_merge_2sty(opt, mk("cnt"), mk("char", True), mk("back", True), start_step=49)
+    for a, b in zip(full, lean):
+        assert {k: v for k, v in a.items() if not (k.endswith("_q_sty1") or k.endswith("_q_sty2"))} == b
