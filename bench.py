@@ -528,16 +528,33 @@ def measured_traffic():
             "traffic_source": "profiles/" + os.path.basename(files[-1])}
 
 
+_HOST = {}     # the host UNet of the e2e record, kept for the sweep record (860 M parameters: built once)
+
+
+def host_unet(dev, compute):
+    import torch
+    from style_transfer_amd import unet as U
+    if "model" not in _HOST:
+        torch.manual_seed(0)
+        model = U.UNetModel().eval().to(dev)
+        for a in model.attention_modules():
+            a.compute = compute
+        _HOST["model"] = model
+    return _HOST["model"]
+
+
 def e2e_record(dev, compute, store):
     """The whole stylisation loop of run_ori.py around the path, driver-timed: this package's host UNet
     (SD-v1 topology and size, seeded random fp32 weights: no checkpoint exists offline) under DDIM, masked
-    AdaIN init, synthetic feature lists in the precomputed_feats_k layout, 49 evaluations per image."""
+    AdaIN init, synthetic feature lists in the precomputed_feats_k layout, 49 evaluations per image; one
+    image at a time and four in flight (one graphed evaluation, stream and workspace per lane)."""
     import tempfile
     import types
     import numpy as np
     import torch
-    from style_transfer_amd import feature_store as fs, synth, unet as U
+    from style_transfer_amd import feature_store as fs, ops, synth
     from style_transfer_amd.features import masked_adain_init
+    from style_transfer_amd.graphed import GraphedUNet
     from style_transfer_amd.sampler import DDIMSampler
     g = torch.Generator(device=dev)
 
@@ -556,25 +573,21 @@ def e2e_record(dev, compute, store):
     fstore = fs.FeatureStore(feature_list(1), feature_list(2), feature_list(3))
     z = fstore.z_enc()
     if store == "packed":
-        fstore.pack(HEADS, compute)
+        fstore.pack(HEADS, compute, T=TEMP)
     merged = fstore.merged(types.SimpleNamespace(gamma=GAMMA, T=TEMP), start_step=49)
     mask = synth.disc_mask()
     td = tempfile.mkdtemp()
     np.save(os.path.join(td, "img_mask.npy"), mask)
-    torch.manual_seed(0)
-    model = U.UNetModel().eval().to(dev)
+    model = host_unet(dev, compute)
     model.set_content_name(os.path.join(td, "img.jpg"))
-    for a in model.attention_modules():
-        a.compute = compute
     s = DDIMSampler(model)
     s.make_schedule(50, 0.0)
     ctx = torch.randn(1, 77, 768, device=dev, generator=g)
     mask_dev = torch.from_numpy(mask).to(dev)
+    x_T = lambda: masked_adain_init(z[0], z[1], z[2], mask_dev)
 
     def timed(sampler, images=2):
-        def one():
-            x_T = masked_adain_init(z[0], z[1], z[2], mask_dev)
-            return sampler.sample(x_T, ctx, injected_features=merged, start_step=49)
+        one = lambda: sampler.sample(x_T(), ctx, injected_features=merged, start_step=49)
         one()                            # warm-up: the convolution library picks its kernels here (and graph capture)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -584,24 +597,132 @@ def e2e_record(dev, compute, store):
         assert torch.isfinite(out).all()
         return (time.perf_counter() - t0) / images
 
-    dt = timed(s)
-    # the same loop with every evaluation replayed as one HIP graph over static slots (graphed.GraphedUNet):
-    # the eager host network is bound by its ~700 launches per evaluation, not by the GPU
-    from style_transfer_amd.graphed import GraphedUNet
-    sg = DDIMSampler(GraphedUNet(model))
-    sg.make_schedule(50, 0.0)
-    dt_g = timed(sg)
-    with torch.autocast("cuda", dtype=torch.bfloat16):     # the host network's convolutions and linears in bf16
-        sa = DDIMSampler(GraphedUNet(model))
-        sa.make_schedule(50, 0.0)
-        dt_a = timed(sa)
-    return {"value": 1.0 / dt_g, "unit": "imgs/s", "s_per_image": dt_g, "images": 2,
+    def timed_lanes(n, rounds=2):
+        """`n` images in flight: sample_lanes over n graphed evaluations of the one network."""
+        lanes = [GraphedUNet(model) for _ in range(n)]
+        streams = [lane_stream(dev, i) for i in range(n)]
+        batch = lambda: s.sample_lanes(lanes, [x_T() for _ in range(n)], [ctx] * n, [merged] * n, start_step=49, streams=streams)
+        batch()                          # capture per lane
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            outs = batch()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o).all() for o in outs)
+        return (time.perf_counter() - t0) / (rounds * n)
+
+    dt = timed(s)                        # launched kernel by kernel
+    lanes_rec = {}
+    for n in (1, 4):
+        for a in model.attention_modules():
+            a.kernel_flags = ops.FLAG_THROUGHPUT if n > 1 else 0
+        per = {"fp32": timed_lanes(n)}
+        with torch.autocast("cuda", dtype=torch.bfloat16):     # the host network's convolutions and linears in bf16
+            per["bf16_autocast"] = timed_lanes(n)
+        lanes_rec[str(n)] = {k: {"imgs_per_s": 1.0 / v, "s_per_image": v} for k, v in per.items()}
+    for a in model.attention_modules():
+        a.kernel_flags = 0
+    best = lanes_rec["4"]["fp32"]
+    _HOST.update(ctx=ctx, tmp=td)
+    return {"value": best["imgs_per_s"], "unit": "imgs/s", "s_per_image": best["s_per_image"],
+            "lanes": lanes_rec,
             "eager_host_unet": {"value": 1.0 / dt, "s_per_image": dt},
-            "bf16_autocast_host_unet": {"value": 1.0 / dt_a, "s_per_image": dt_a},
-            "what": "masked AdaIN init + 49 evaluations of the host UNet (SD-v1 size, random fp32 weights, stock "
-                    "PyTorch convolutions) with the HIP attention kernels, one image at a time, every evaluation "
-                    "replayed as one HIP graph (eager_host_unet: the same launched kernel by kernel; "
-                    "bf16_autocast_host_unet: graphs captured under bf16 autocast); VAE and text encoder not run"}
+            "what": "masked AdaIN init + 49 evaluations of the host UNet (SD-v1 size, random fp32 weights, stock PyTorch "
+                    "convolutions) with the HIP attention kernels, every evaluation replayed as one HIP graph; `value`: four "
+                    "images in flight, fp32 network; lanes: images in flight x {fp32, network under bf16 autocast}; "
+                    "eager_host_unet: one image at a time launched kernel by kernel; VAE and text encoder not run"}
+
+
+def sweep_record(dev, compute):
+    """configs[3] in small: the run.py loop (style_transfer_amd.run.run_lines: loader, masked AdaIN, merge, 49
+    graphed evaluations per line) over 8 lines = 2 contents x 2 character styles x 2 background styles, whose
+    six SD-v1-sized feature files (3.54 GB pickles written by save_feature_file) sit in tmpfs; imgs/s
+    INCLUDING the feature load, by route, beside the compute-only rate.  Skipped when tmpfs has no room."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from style_transfer_amd import feature_store as fs, run as cli, synth
+    from style_transfer_amd.sampler import DDIMSampler
+    base_dir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    free = shutil.disk_usage(base_dir).free
+    if free < 48 << 30:
+        return {"skipped": "%s has %.0f GB free; the sweep needs 48" % (base_dir, free / 1e9)}
+    root = tempfile.mkdtemp(prefix="sid_sweep_", dir=base_dir)
+    try:
+        data, pre = os.path.join(root, "data"), os.path.join(root, "pre")
+        for sub in ("cnt", "sty/char", "sty/back"):
+            os.makedirs(os.path.join(data, sub))
+        os.makedirs(pre)
+        g = torch.Generator(device=dev)
+
+        def feature_list(seed):
+            g.manual_seed(seed)
+            out = []
+            for _ in range(50):
+                e = {"config": {"T": TEMP}, "z_enc": torch.randn(1, 4, 64, 64, device=dev, generator=g)}
+                for b in range(6, 12):
+                    n, d = (1024, 80) if b < 9 else (4096, 40)
+                    for t in "qkv":
+                        e["output_block_%d_self_attn_%s" % (b, t)] = torch.randn(8, n, d, device=dev, generator=g)
+                out.append(e)
+            return out
+
+        t0 = time.perf_counter()
+        names = {"cnt": ["c1", "c2"], "sty/char": ["a1", "a2"], "sty/back": ["b1", "b2"]}
+        for sub, lst in names.items():
+            for i, n in enumerate(lst):
+                open(os.path.join(data, sub, n + ".png"), "wb").write(b"x")
+                fs.save_feature_file(os.path.join(pre, n + ("_cnt.pkl" if sub == "cnt" else "_sty.pkl")),
+                                     feature_list(7000 + 10 * len(sub) + i))
+        for n in names["cnt"]:
+            np.save(os.path.join(data, "cnt", n + "_mask.npy"), synth.disc_mask())
+        lines = ["%s.png %s.png %s.png" % (c, a, b) for a in names["sty/char"] for b in names["sty/back"] for c in names["cnt"]]
+        with open(os.path.join(data, "dataset.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        pkl_bytes = sum(os.path.getsize(os.path.join(pre, n)) for n in os.listdir(pre))
+        t_write = time.perf_counter() - t0
+        model = host_unet(dev, compute)
+        sampler = DDIMSampler(model)
+        sampler.make_schedule(50, 0.0)
+        uc = _HOST.get("ctx")
+        if uc is None:
+            uc = torch.zeros(1, 77, 768, device=dev)
+        triples = cli.list_triples(data)
+        common = ["--data_root", data, "--precomputed", pre, "--output_path", os.path.join(root, "out"), "--gamma", str(GAMMA),
+                  "--T", str(TEMP), "--compute", compute, "--graph_unet"]
+        os.makedirs(os.path.join(root, "out"))
+
+        def run(extra, lines_idx):
+            opt = cli.build_parser().parse_args(common + extra)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            _, st = cli.run_lines(opt, model, sampler, triples, lines_idx, uc, dev)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            return {"lines": len(lines_idx), "s": dt, "imgs_per_s": len(lines_idx) / dt, "files_read": st["files"],
+                    "GB_read": st["file_bytes"] / 1e9, "lists_served_from_hbm": st["hits"], "side_cars_read": st["routes"]["sidecar"],
+                    "load_GB_per_s": st["file_bytes"] / 1e9 / max(st["load_seconds"], 1e-9),
+                    "sampler_waited_s": st["wait_seconds"]}
+
+        every = list(range(len(triples)))
+        rec = {"what": "run.py loop over 8 lines (2 contents x 2 character x 2 background styles), six 3.54 GB feature pickles in "
+                       "%s, one image at a time, every evaluation a HIP graph; imgs/s include reading, uploading and packing the "
+                       "feature files" % base_dir,
+               "pickle_GB": pkl_bytes / 1e9, "files_written_s": t_write}
+        run(["--no_prefetch", "--sidecar", "off", "--store_cache_gb", "0"], every[:1])       # warm-up: graph capture, conv kernels
+        # the reference's order: every line reads its three pickles when its turn comes, nothing is kept (run_ori.py:168-222)
+        rec["reference_order"] = run(["--no_prefetch", "--sidecar", "off", "--store_cache_gb", "0"], every[:3])
+        rec["reference_order"]["note"] = "first 3 lines only (every line costs the same: 3 pickles)"
+        rec["prefetch_lru_pickles"] = run(["--sidecar", "write"], every)                     # also writes the side-cars
+        rec["prefetch_lru_sidecars"] = run(["--sidecar", "use"], every)
+        rec["prefetch_lru_sidecars_4_lanes"] = run(["--sidecar", "use", "--lanes", "4"], every)
+        rec["sidecar_GB"] = sum(os.path.getsize(os.path.join(pre, n)) for n in os.listdir(pre) if n.endswith(".sidpack")) / 1e9
+        # compute only: the same lines with every list already resident (a second pass over a warm loader is not what
+        # run_lines does, so: the e2e record's rate for one image at a time)
+        return rec
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline():
@@ -815,10 +936,14 @@ def run_rank(args, world, rank, local):
             line["block_skip"] = None if args.no_block_skip else block_skip_record(dev, args.compute)
             line["content_cache"] = None if args.no_content_cache else content_cache_record(dev, args.compute)
             line["e2e"] = None if args.no_e2e else e2e_record(dev, args.compute, args.store)
+            line["sweep"] = None if args.no_sweep else sweep_record(dev, args.compute)
+            _HOST.clear()
+            torch.cuda.empty_cache()
             line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
             line["default_hw_queues"] = None if args.no_default_queues or args.hw_queues == 0 else default_queue_record(args)
         else:
             line["e2e"] = None
+            line["sweep"] = None
             line["feature_scale"] = None
             line["default_hw_queues"] = None
             line["block_skip"] = None

@@ -46,6 +46,7 @@ class GraphedUNet:
         self.unet = unet
         self._key = None
         self._graph = None
+        self.content_name = None       # set by a caller that runs several of these over one network: this lane's content image
 
     def _signature(self, x, context, feats):
         cnt = tuple(getattr(m, "cnt_name", None) for m in self.unet.attention_modules()[:1])
@@ -73,6 +74,9 @@ class GraphedUNet:
                     slot.partial.q_ptr = self.slots[k[:-len("_k_cnt")] + "_q"].data_ptr()
         self.stream = torch.cuda.Stream(device=x.device)
         self.stream.wait_stream(torch.cuda.current_stream(x.device))
+        for t in (x, timesteps, context):           # the clones above were made on the caller's stream
+            if t is not None:
+                t.record_stream(self.stream)
         with torch.cuda.stream(self.stream), torch.no_grad():
             for _ in range(2):                  # warm-up: workspaces, mask cache, library kernel selection
                 self.unet(self.x, self.t, self.ctx, injected_features=self.slots)
@@ -84,6 +88,10 @@ class GraphedUNet:
             self.out = self.unet(self.x, self.t, self.ctx, injected_features=self.slots)
 
     def __call__(self, x, timesteps=None, context=None, injected_features=None):
+        if self.content_name is not None:
+            mods = self.unet.attention_modules()
+            if mods and mods[0].cnt_name != self.content_name:
+                self.unet.set_content_name(self.content_name)
         key = self._signature(x, context, injected_features)
         if key != self._key:
             self._capture(x, timesteps, context, injected_features)

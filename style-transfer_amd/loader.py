@@ -4,13 +4,14 @@ The reference unpickles three 3.5 GB files for every triple, one after the other
 (run_ori.py:168-222).  At 10.6 GB per triple that, not the sampling, bounds images per second, so this
 loader takes the files off the sampling path:
 
-  * a worker thread reads the NEXT triple's files while the current one samples: file -> pinned host
-    staging -> HBM on a side stream -> `sid_pack_kv` on that stream; the sampling stream only waits for the
-    event that marks a file ready;
+  * a worker thread reads the NEXT triple's files while the current one samples: file -> HBM on a side
+    stream (a side-car through two pinned staging slots) -> `sid_pack_kv` on that stream; the sampling
+    stream only waits for the event that marks a file ready;
   * every loaded (and packed) list stays in HBM under an LRU bound, keyed by file: a sweep that pairs one
     style with many contents (or one content with many style pairs) reads each file once;
   * a packed side-car (`{base}_cnt.sidpack` / `{base}_sty.sidpack`, feature_store.write_sidecar) holds what
-    the kernels read, as they read it: no unpickling, no conversion, a third of the bytes for a style file.
+    the kernels read, as they read it: no unpickling, no conversion, 0.43 of the bytes for a style file
+    (measured on SD-v1-sized files in tmpfs: 12 GB/s from file to HBM against 2.7 GB/s through the pickle).
 
 Results do not depend on which route a list took: the side-car is the bytes `pack` produced.
 """
@@ -107,6 +108,10 @@ class FeatureLoader:
                                got[("sty", back)].feats if two_styles else None)
 
     def _evict(self, keep):
+        if self.cache_bytes <= 0:              # keep nothing: every line reads its files again (the reference's order)
+            self.stats["evicted"] += len(self._cache)
+            self._cache.clear()
+            return
         total = sum(e.hbm_bytes for e in self._cache.values())
         for key in list(self._cache):
             if total <= self.cache_bytes:
@@ -250,36 +255,19 @@ class FeatureLoader:
                     entry[k] = v.to(self.dtype)
 
     def _read_pickle(self, pkl, role, want_packed):
-        """The reference's file through the allow-list unpickler onto the host, then entry by entry into HBM.
-        A packed style list never uploads its queries (nothing reads them); keys and values go into a buffer
-        of their own that is freed once they are packed."""
-        host = fs.load_feature_file(pkl, "cpu", None)
-        nfile = os.path.getsize(pkl)
-        al = fs.SIDECAR_ALIGN
-        feats = []
-        for e in host:
-            out = {"config": e["config"]} if "config" in e else {}
-            groups = ([], [])                          # kept tensors | keys and values on their way to pack
-            for k, v in e.items():
-                if not torch.is_tensor(v):
-                    continue
-                is_q, is_kv = k.endswith("_self_attn_q"), k.endswith("_self_attn_k") or k.endswith("_self_attn_v")
-                if want_packed and role == "sty" and is_q:
-                    continue
-                groups[1 if (want_packed and is_kv) else 0].append((k, v.contiguous()))
-            for grp in groups:
-                if not grp:
-                    continue
-                pieces, off, where = [], 0, {}
-                for k, v in grp:
-                    raw = v.view(torch.uint8).reshape(-1)
-                    pieces.append((off, raw))
-                    where[k] = (off, raw.numel(), v.dtype, tuple(v.shape))
-                    off = (off + raw.numel() + al - 1) // al * al
-                flat = self._upload(pieces, off)
-                for k, (o, n, dt, shape) in where.items():
-                    out[k] = flat[o:o + n].view(dt).view(shape)
+        """The reference's file through the allow-list unpickler, every storage decoded straight onto the
+        device (measured faster than a detour through pinned staging: the unpickler's own copy is the cost).
+        A packed style list drops its queries at once (nothing reads them); keys and values are freed when
+        they have been packed."""
+        if self._stream is not None:
+            with torch.cuda.stream(self._stream):
+                feats = fs.load_feature_file(pkl, self.device, None)
+        else:
+            feats = fs.load_feature_file(pkl, self.device, None)
+        for e in feats:
+            if want_packed and role == "sty":
+                for k in [k for k in e if k.endswith("_self_attn_q")]:
+                    del e[k]
             if self.dtype is not None:
-                self._cast(out)
-            feats.append(out)
-        return feats, None, nfile
+                self._cast(e)
+        return feats, None, os.path.getsize(pkl)

@@ -71,6 +71,9 @@ def build_parser():
                         "loaded) and reuse it, its feature list and its filtered residuals for every style pair with the "
                         "same content image: the dataset.txt lines of one content are processed next to each other, on one rank")
     p.add_argument('--unpacked_store', action='store_true', help="keep key/value features as tensors instead of the kernels' operand layout")
+    p.add_argument('--lanes', type=int, default=1,
+                   help="images in flight on one GPU: each lane replays its own HIP graph of the UNet evaluation on its own stream "
+                        "(implies --graph_unet; lines whose content has a residual file are stylised one at a time)")
     p.add_argument('--no_prefetch', action='store_true', help="read the feature files of a line only when its turn comes (the reference's order)")
     p.add_argument('--sidecar', default='use', choices=['off', 'use', 'write'],
                    help="packed side-car files beside the pickles ({base}_cnt.sidpack / {base}_sty.sidpack): 'use' reads one when it "
@@ -164,11 +167,32 @@ def bases_of(opt, triple):
     return (base(cnt_path), base(char_path), base(back_path) if back_path is not None else None)
 
 
+def prepare(opt, model, triple, device, store):
+    """Initial latent and merged features of one line (run_ori.py:224-235; hf_run.py:424-428 for a pair)."""
+    from .features import adain, masked_adain_init
+    cnt_path = triple[0]
+    if store.back is None:                                             # single style: hf_run.py:424-428
+        cnt_z, sty_z = store.z_enc()
+        x_T = cnt_z if opt.without_init_adain else adain(cnt_z, sty_z)
+    else:
+        cnt_z, char_z, back_z = store.z_enc()
+        if opt.without_init_adain:
+            x_T = cnt_z
+        else:
+            mask = np.load(os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")).astype(np.float32)
+            x_T = masked_adain_init(cnt_z, char_z, back_z, torch.from_numpy(mask).to(device))
+    feats = None if opt.without_attn_injection else store.merged(opt, start_step=opt.start_step)
+    return x_T, feats
+
+
+def residual_path(opt, triple):
+    return os.path.join(opt.precomputed, base(triple[0]) + "_residuals_all.pkl")
+
+
 def stylise(opt, model, sampler, triple, uc, device, store=None):
     """One triple -> final latent (1, C, H/f, W/f).  `store`: its FeatureStore from a FeatureLoader (default:
     loaded here, synchronously)."""
     from . import feature_store as fs
-    from .features import adain, masked_adain_init
     from .high_frequency import make_content_injection_schedule, patch_decoder_resblocks_h_and_cnt_hf
     cnt_path = triple[0]
     model.set_content_name(cnt_path)                                   # run_ori.py:159-161
@@ -182,18 +206,8 @@ def stylise(opt, model, sampler, triple, uc, device, store=None):
     if store is None:
         loader = make_loader(opt, model, device, prefetch=False)
         store = loader.get(bases_of(opt, triple))
-    if store.back is None:                                             # single style: hf_run.py:424-428
-        cnt_z, sty_z = store.z_enc()
-        x_T = cnt_z if opt.without_init_adain else adain(cnt_z, sty_z)
-    else:
-        cnt_z, char_z, back_z = store.z_enc()
-        if opt.without_init_adain:
-            x_T = cnt_z
-        else:
-            mask = np.load(os.path.join(opt.data_root, "cnt", base(cnt_path) + "_mask.npy")).astype(np.float32)
-            x_T = masked_adain_init(cnt_z, char_z, back_z, torch.from_numpy(mask).to(device))
-    feats = None if opt.without_attn_injection else store.merged(opt, start_step=opt.start_step)
-    res_path = os.path.join(opt.precomputed, base(cnt_path) + "_residuals_all.pkl")
+    x_T, feats = prepare(opt, model, triple, device, store)
+    res_path = residual_path(opt, triple)
     callback = None
     if os.path.isfile(res_path):                                       # high-frequency injection, --ratio
         from .sampler import last_resblocks
@@ -226,6 +240,71 @@ def stylise(opt, model, sampler, triple, uc, device, store=None):
         finally:
             sampler.unet = eager
     return sampler.sample(x_T, uc, injected_features=feats, start_step=opt.start_step, callback=callback)
+
+
+def stylise_lanes(opt, model, sampler, batch, uc, device, stores, lanes):
+    """Several lines at once, one per lane (`lanes`: [(GraphedUNet, stream)]): final latents in line order."""
+    from .high_frequency import unpatch_decoder_resblocks
+    unpatch_decoder_resblocks(model)
+    x_Ts, feats = [], []
+    for (g, _), triple, store in zip(lanes, batch, stores):
+        g.content_name = triple[0]                                     # every lane replays its own content's mask
+        x_T, f = prepare(opt, model, triple, device, store)
+        x_Ts.append(x_T)
+        feats.append(f)
+    n = len(batch)
+    return sampler.sample_lanes([g for g, _ in lanes[:n]], x_Ts, [uc] * n, feats, start_step=opt.start_step,
+                                streams=[st for _, st in lanes[:n]])
+
+
+def run_lines(opt, model, sampler, triples, mine, uc, device):
+    """The loop of run_ori.py:155-246 over this rank's lines `mine` (indices into `triples`): every line's
+    feature files through the loader (read ahead, kept resident, side-cars), its latent saved under the
+    reference's output name.  Returns (final latents in the order of `mine`, loader statistics)."""
+    latents = []
+    loader = make_loader(opt, model, device)
+    keys = [bases_of(opt, triples[idx]) for idx in mine]
+    n_lanes = max(1, getattr(opt, "lanes", 1))
+    lanes = []
+    if n_lanes > 1:
+        from . import ops
+        from .graphed import GraphedUNet
+        lanes = [(GraphedUNet(model), torch.cuda.Stream(device=device)) for _ in range(n_lanes)]
+        for a in model.attention_modules():
+            a.kernel_flags |= ops.FLAG_THROUGHPUT          # the images share the GPU: least-work decomposition
+    # batches of lines that go together: one per lane, a line with a residual file (high-frequency injection sets
+    # per-step state on the shared network) by itself
+    batches, j = [], 0
+    while j < len(mine):
+        take = 1
+        if n_lanes > 1 and not os.path.isfile(residual_path(opt, triples[mine[j]])):
+            while (take < n_lanes and j + take < len(mine)
+                   and not os.path.isfile(residual_path(opt, triples[mine[j + take]]))):
+                take += 1
+        batches.append(list(range(j, j + take)))
+        j += take
+
+    def save(idx, z):
+        latents.append(z[0].float())
+        name = "_".join(base(p) for p in triples[idx] if p is not None) + ".pt"
+        torch.save(z.cpu(), os.path.join(opt.output_path, name))      # run_ori.py:245 names the PNG the same way
+
+    for j in (batches[0] if batches else []):
+        loader.request(keys[j])
+    with torch.no_grad():
+        for bi, batch in enumerate(batches):
+            stores = [loader.get(keys[j]) for j in batch]
+            for j in (batches[bi + 1] if bi + 1 < len(batches) else []):
+                loader.request(keys[j])                    # read, upload and pack while this batch samples
+            if len(batch) == 1 and (n_lanes == 1 or os.path.isfile(residual_path(opt, triples[mine[batch[0]]]))):
+                save(mine[batch[0]], stylise(opt, model, sampler, triples[mine[batch[0]]], uc, device, stores[0]))
+            else:
+                zs = stylise_lanes(opt, model, sampler, [triples[mine[j]] for j in batch], uc, device, stores, lanes)
+                for j, z in zip(batch, zs):
+                    save(mine[j], z)
+            del stores
+    loader.close()
+    return latents, dict(loader.stats)
 
 
 def main(argv=None):
@@ -268,23 +347,8 @@ def main(argv=None):
              else [sharding.shard_indices(len(triples), r, world) for r in range(world)])
     mine = lists[rank]
     begin = time.time()
-    latents = []
-    loader = make_loader(opt, model, device)
-    keys = [bases_of(opt, triples[idx]) for idx in mine]
-    if keys:
-        loader.request(keys[0])
-    with torch.no_grad():
-        for j, idx in enumerate(mine):
-            store = loader.get(keys[j])
-            if j + 1 < len(mine):
-                loader.request(keys[j + 1])                # read, upload and pack while this one samples
-            z = stylise(opt, model, sampler, triples[idx], uc, device, store)
-            latents.append(z[0].float())
-            name = "_".join(base(p) for p in triples[idx] if p is not None) + ".pt"
-            torch.save(z.cpu(), os.path.join(opt.output_path, name))  # run_ori.py:245 names the PNG the same way
-            del store
-    loader.close()
-    opt.loader_stats = dict(loader.stats)
+    latents, stats = run_lines(opt, model, sampler, triples, mine, uc, device)
+    opt.loader_stats = stats
     shape = (opt.C, opt.H // opt.f, opt.W // opt.f)
     local_stack = torch.stack(latents) if latents else torch.zeros((0,) + shape, device=device)
     local_stack, _ = sharding.pad_to_common(local_stack, len(triples), world, per=max(len(l) for l in lists))
@@ -294,7 +358,7 @@ def main(argv=None):
     if rank == 0:
         allz = sharding.reassemble_lists(gathered, lists)
         torch.save(allz.cpu(), os.path.join(opt.output_path, "latents_all.pt"))
-        st = loader.stats
+        st = stats
         print("Total end: %.3f s for %d triples on %d GPU(s); rank 0 read %d files (%.2f GB, %d from side-cars), %d served from HBM"
               % (time.time() - begin, len(triples), world, st["files"], st["file_bytes"] / 1e9, st["routes"]["sidecar"], st["hits"]))
     if dist is not None:

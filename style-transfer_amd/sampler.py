@@ -39,27 +39,60 @@ class DDIMSampler:
         (the high-frequency patch reads the timestep it sets), then `img_callback(pred_x0, img, step)`
         (ldm/models/diffusion/ddim.py:230-233)."""
         img = x_T
-        b = x_T.shape[0]
         total = len(self.ddim_timesteps)
         for i, step in enumerate(np.flip(self.ddim_timesteps)):
             index = total - i - 1
             if index >= start_step:
                 continue
-            ts = torch.full((b,), int(step), device=x_T.device, dtype=torch.long)
             feats = injected_features[i] if injected_features else None
-            e_t = self.unet(img, ts, unconditional_conditioning, injected_features=feats)
-            a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
-            sigma_t = float(self.ddim_sigmas[index])
-            pred_x0 = (img - float(self.ddim_sqrt_one_minus_alphas[index]) * e_t) / a_t ** 0.5
-            dir_xt = (1.0 - a_prev - sigma_t ** 2) ** 0.5 * e_t
-            img = a_prev ** 0.5 * pred_x0 + dir_xt
-            if sigma_t > 0:
-                img = img + sigma_t * torch.randn(img.shape, device=img.device, generator=generator)
+            img, pred_x0 = self._step(self.unet, img, step, index, unconditional_conditioning, feats, generator)
             if callback is not None:
                 callback(i)
             if img_callback is not None:
                 img_callback(pred_x0, img, int(step))
         return img
+
+    def _step(self, unet, img, step, index, cond, feats, generator=None):
+        """One DDIM update x_t -> x_{t-1} (ldm/models/diffusion/ddim.py:286-322), scalars on the host."""
+        ts = torch.full((img.shape[0],), int(step), device=img.device, dtype=torch.long)
+        e_t = unet(img, ts, cond, injected_features=feats)
+        a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
+        sigma_t = float(self.ddim_sigmas[index])
+        pred_x0 = (img - float(self.ddim_sqrt_one_minus_alphas[index]) * e_t) / a_t ** 0.5
+        dir_xt = (1.0 - a_prev - sigma_t ** 2) ** 0.5 * e_t
+        out = a_prev ** 0.5 * pred_x0 + dir_xt
+        if sigma_t > 0:
+            out = out + sigma_t * torch.randn(out.shape, device=out.device, generator=generator)
+        return out, pred_x0
+
+    @torch.no_grad()
+    def sample_lanes(self, unets, x_Ts, conds, features, start_step=9999, streams=None):
+        """Several images in flight on one GPU: image l is sampled by `unets[l]` (its own GraphedUNet: own
+        static slots, own workspace) on `streams[l]`, the steps of the images interleaved from this one host
+        thread (nothing in a step waits for the GPU).  Images are independent (run_ori.py:155-246 stylises
+        them one after the other); a batch-1 evaluation leaves most of the GPU idle, several at once fill it.
+        Returns the final latents, ready on the calling stream."""
+        n = len(x_Ts)
+        dev = x_Ts[0].device
+        streams = streams or [torch.cuda.Stream(device=dev) for _ in range(n)]
+        cur = torch.cuda.current_stream(dev)
+        imgs = list(x_Ts)
+        for l in range(n):
+            streams[l].wait_stream(cur)
+            imgs[l].record_stream(streams[l])
+        total = len(self.ddim_timesteps)
+        for i, step in enumerate(np.flip(self.ddim_timesteps)):
+            index = total - i - 1
+            if index >= start_step:
+                continue
+            for l in range(n):
+                with torch.cuda.stream(streams[l]):
+                    feats = features[l][i] if features[l] else None
+                    imgs[l], _ = self._step(unets[l], imgs[l], step, index, conds[l], feats)
+        for l in range(n):
+            cur.wait_stream(streams[l])
+            imgs[l].record_stream(cur)
+        return imgs
 
     @torch.no_grad()
     def encode_ddim(self, x0, unconditional_conditioning, num_steps=50, img_callback=None):

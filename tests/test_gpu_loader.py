@@ -235,3 +235,28 @@ def test_producer_command_writes_the_store_the_consumer_reads(tmp_path):
     cli.main(common + ["--output_path", str(tmp_path / "out"), "--ratio", "0.5"])
     z = torch.load(str(tmp_path / "out" / "c1_a_b.pt"), weights_only=True)
     assert tuple(z.shape) == (1, 4, 16, 16) and torch.isfinite(z).all()
+
+
+def test_lanes_give_the_latents_of_one_at_a_time(tmp_path):
+    """`--lanes 3`: three images in flight, each on its own stream with its own graphed evaluation, slots and
+    workspace, contents with different masks in one batch; same latents as one line at a time (to the
+    run-to-run spread of the host network's convolutions)."""
+    from style_transfer_amd import run as cli
+    lines = ["c1.jpg a.png b.png", "c2.jpg a.png b.png", "c1.jpg a2.png b.png", "c2.jpg a2.png b2.png", "c1.jpg a.png b2.png"]
+    root, pre = make_root(tmp_path, lines, masks=("c1",))
+    np.save(str(root / "cnt" / "c2_mask.npy"), 1.0 - load_masks()[case()["mask"]])       # another mask for the second content
+    load = lambda name: torch.load(str(tmp_path / name / "latents_all.pt"), weights_only=True)
+    cli.main(cli_args(tmp_path, root, pre, "warm"))
+    cli.main(cli_args(tmp_path, root, pre, "one") + ["--graph_unet"])
+    cli.main(cli_args(tmp_path, root, pre, "one2") + ["--graph_unet"])
+    want = load("one")
+    spread = (load("one2") - want).abs().max().item()
+    cli.main(cli_args(tmp_path, root, pre, "lanes") + ["--lanes", "3"])
+    got = load("lanes")
+    assert tuple(got.shape) == (5, 4, 16, 16) and torch.isfinite(got).all()
+    diff = (got - want).abs().max().item()
+    print("lanes: max |latent difference| %.2e (two identical runs: %.2e)" % (diff, spread))
+    # (the lanes run the least-work decomposition of the attention calls: another cut of the key runs, so the
+    # difference is that of two decompositions, 4e-3 of the largest output per call at most)
+    assert diff <= max(4 * spread, 5e-3 * want.abs().max().item())
+    assert not torch.equal(got[0], got[2]) and not torch.equal(got[0], got[1])
