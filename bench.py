@@ -273,6 +273,18 @@ def kernel_records(w, compute):
                     ("pre-packed by the feature store: query pack + flash + merge" if w["store"] == "packed"
                      else "packed per call: pack + flash + merge")}
     roof.update(measured_traffic())
+    if compute == "f16" and w["store"] == "packed":
+        # the same stage with bf16 operands for q.k^T (the arithmetic of earlier rounds' headline, selectable with
+        # --compute bf16): the half-precision multipliers cost a few per cent of clock
+        import torch
+        gen = torch.Generator(device=layer["mask"].device); gen.manual_seed(99)
+        rn = lambda *sh: torch.randn(*sh, device=layer["mask"].device, generator=gen)
+        alt = {"N": 4096, "d": 40, "xq": [rn(1, 4096, HEADS * 40)], "mask": layer["mask"],
+               "feats": [(rn(HEADS, 4096, 40), [ops.pack_kv(rn(HEADS, 4096, 40), rn(HEADS, 4096, 40), HEADS, "bf16") for _ in range(3)])]}
+        injected_call(alt, 0, "bf16")
+        t_alt = eager_events_per_call(lambda: injected_call(alt, 0, "bf16", flags=0x20), 300)
+        roof["bf16_operands"] = {"kernel": "sid_attn::flash_kernel<3,2,2,false,2,8,true,false,false>", "kernel_ms": t_alt * 1e3,
+                                 "achieved": flops / t_alt / 1e12, "frac": flops / t_alt / MFMA_PEAK}
     hf = {"bound": "hbm", "kernel": "sid_hf::hf2_kernel fused skip + h + HF(h_cnt), (1,320,64,64) f32", "kernel_ms": t_hf * 1e3,
           "achieved": hf_bytes / t_hf / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hf_bytes / t_hf / HBM_PEAK,
           "algorithmic_bytes": hf_bytes,
@@ -853,13 +865,16 @@ def run_rank(args, world, rank, local):
 
     for i in range(args.warmup):
         one_image(i)
-    # Warm-up of the job's one collective, with the shape the timed gather will have: the first gather of a
-    # process group sets up its point-to-point channels, and the first all_reduce its ring; neither belongs
-    # to the timed region (with 20 images the region is under half a second).
+    # Rehearsal of the region's tail with the shapes it will have: the stack of `steps` latents (the allocator
+    # gets its block now, not inside the region) and the job's one collective: the first gather of a process
+    # group sets up its point-to-point channels, and the first all_reduce its ring; none of that belongs to the
+    # timed region (with 20 images the region is under half a second).
+    dummy = to_wire(torch.stack([torch.zeros(4 * 64 * 64, device=dev) for _ in range(args.steps)]).float())
     if dist is not None:
-        dummy = to_wire(torch.zeros(args.steps, 4 * 64 * 64, device=dev))
         note("gather")
-        sharding.gather_latents(dummy, dist, dst=0)
+    sharding.gather_latents(dummy, dist, dst=0)
+    del dummy
+    if dist is not None:
         tw = torch.zeros(1, device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         note("all_reduce")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
