@@ -333,39 +333,42 @@ def block_skip_record(dev, compute):
                                  "content_segments_logits_only": counts[1], "of_those_redone_in_full": counts[2]})
             del xq, q_cnt, kv, out
             torch.cuda.empty_cache()
-    # the whole hot path of an image, three images in flight, at the feature-sized logits: the headline's
+    # the whole hot path of an image, images in flight as in `value`, at feature-sized logits (x2 and x3): the headline's
     # loop with and without the flag (only the three N = 4096 injected layers are long enough to take it)
     n_lanes, images = max(len(_LANE_STREAMS), 1), 12
-    lanes = []
-    for li in range(n_lanes):
-        gen.manual_seed(4300 + li)
-        w = make_image_workload(dev, gen, torch.float32, "packed", mode, sigma=3.0)
-        st = lane_stream(dev, li)
-        graphs = {}
-        for name, fl in (("off", ops.FLAG_THROUGHPUT), ("on", ops.FLAG_THROUGHPUT | ops.FLAG_BLOCK_SKIP)):
-            with torch.cuda.stream(st):
-                run_image(w, mode, fl)
-            torch.cuda.synchronize()
-            graphs[name] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graphs[name], stream=st, capture_error_mode="thread_local"):
-                run_image(w, mode, fl)
-        lanes.append((st, graphs, w))
-    rates = {}
-    for name in ("off", "on"):
-        for timed in (False, True):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(images):
-                st, graphs, _ = lanes[i % n_lanes]
+    rec["image"] = []
+    for sigma in (2.0, 3.0):
+        lanes = []
+        for li in range(n_lanes):
+            gen.manual_seed(4300 + li)
+            w = make_image_workload(dev, gen, torch.float32, "packed", mode, sigma=sigma)
+            st = lane_stream(dev, li)
+            graphs = {}
+            for name, fl in (("off", ops.FLAG_THROUGHPUT), ("on", ops.FLAG_THROUGHPUT | ops.FLAG_BLOCK_SKIP)):
                 with torch.cuda.stream(st):
-                    graphs[name].replay()
-            torch.cuda.synchronize()
-            if timed:
-                rates[name] = images / (time.perf_counter() - t0)
-    rec["image"] = {"what": "hot path of one image as in `value` (same lanes), attention tensors x3 (feature-sized logits)",
-                    "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"], "ratio": rates["on"] / rates["off"]}
-    del lanes
-    torch.cuda.empty_cache()
+                    run_image(w, mode, fl)
+                torch.cuda.synchronize()
+                graphs[name] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graphs[name], stream=st, capture_error_mode="thread_local"):
+                    run_image(w, mode, fl)
+            lanes.append((st, graphs, w))
+        rates = {}
+        for name in ("off", "on"):
+            for timed in (False, True):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(images):
+                    st, graphs, _ = lanes[i % n_lanes]
+                    with torch.cuda.stream(st):
+                        graphs[name].replay()
+                torch.cuda.synchronize()
+                if timed:
+                    rates[name] = images / (time.perf_counter() - t0)
+        rec["image"].append({"what": "hot path of one image as in `value` (same lanes), attention tensors x%g (feature-sized logits)" % sigma,
+                             "feature_sigma": sigma, "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"],
+                             "ratio": rates["on"] / rates["off"]})
+        del lanes
+        torch.cuda.empty_cache()
     return rec
 
 
@@ -536,8 +539,18 @@ def measured_traffic():
     # mfma_busy: matrix-pipe busy cycles over the dispatch's SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES against
     # GRBM_GUI_ACTIVE), the hardware's own utilisation figure beside the algorithmic `frac` (which counts
     # neither the padding of head_dim 40 to the MFMA shapes nor the clock the chip sustains)
-    return {"traffic": js.get("traffic_bytes"), "mfma_busy": js.get("mfma_busy"), "valu_issue_busy": js.get("valu_issue_busy"),
-            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    out = {"traffic": js.get("traffic_bytes"), "mfma_busy": js.get("mfma_busy"), "valu_issue_busy": js.get("valu_issue_busy"),
+           "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    # Where a workgroup's time goes, from the diagnostic build's clock stamps (tools/diag_flash.py; not measurable in
+    # the product build, which executes no stamp): time inside the stage loops against the kernel's span, and the
+    # rest of a workgroup's lifetime (first fill, reference pre-pass and row store of each of its segments).
+    phases = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flash_phases.json")))
+    if phases:
+        with open(phases[-1]) as f:
+            ph = json.load(f)
+        out.update(steady_loop_frac=ph.get("steady_loop_frac"), fixed_cost_us=ph.get("fixed_cost_us_per_workgroup"),
+                   phases_source="profiles/" + os.path.basename(phases[-1]))
+    return out
 
 
 _HOST = {}     # the host UNet of the e2e record, kept for the sweep record (860 M parameters: built once)

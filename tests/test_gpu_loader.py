@@ -260,3 +260,43 @@ def test_lanes_give_the_latents_of_one_at_a_time(tmp_path):
     # difference is that of two decompositions, 4e-3 of the largest output per call at most)
     assert diff <= max(4 * spread, 5e-3 * want.abs().max().item())
     assert not torch.equal(got[0], got[2]) and not torch.equal(got[0], got[1])
+
+
+def test_sweep_of_16_lines_over_two_ranks_with_lanes(tmp_path):
+    """The data_vis sweep in small: 16 lines = 4 contents x 2 character x 2 background styles, started the way
+    the driver starts ranks (here both ranks on the one GPU of the box, the gather through the host), two
+    images in flight per rank, side-cars written by a first pass and read by the second.  Rank 0's gathered
+    stack equals the single-process run line by line, and a rank reads each of its files once."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    from style_transfer_amd import run as cli
+    lines = ["c%d.jpg a%d.png b%d.png" % (c, a, b) for a in (1, 2) for b in (1, 2) for c in (1, 2, 3, 4)]
+    root, pre = make_root(tmp_path, lines, masks=("c1", "c2", "c3", "c4"))
+    args = cli_args(tmp_path, root, pre, "one")
+    cli.main(args + ["--sidecar", "write"])
+    single = torch.load(str(tmp_path / "one" / "latents_all.pt"), weights_only=True)
+    assert tuple(single.shape) == (16, 4, 16, 16) and torch.isfinite(single).all()
+    assert len([n for n in os.listdir(str(pre)) if n.endswith(".sidpack")]) == 8
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SID_DIST_BACKEND="gloo", SID_ONE_DEVICE="1", PYTHONPATH=repo + os.pathsep + env.get("PYTHONPATH", ""))
+    two = cli_args(tmp_path, root, pre, "two")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-m", "style_transfer_amd.run"] + two + ["--lanes", "2"],
+                       env=env, cwd=repo, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"16 triples on 2 GPU\(s\); rank 0 read (\d+) files \(([\d.]+) GB, (\d+) from side-cars\), (\d+) served from HBM", r.stdout)
+    assert m, r.stdout[-500:]
+    files, _, from_side, hits = int(m.group(1)), float(m.group(2)), int(m.group(3)), int(m.group(4))
+    # rank 0 takes lines 0, 2, 4, ...: contents c1 and c3, all four styles: 6 files, each read once, all from side-cars
+    assert files == 6 and from_side == 6 and hits == 8 * 3 - 6
+    both = torch.load(str(tmp_path / "two" / "latents_all.pt"), weights_only=True)
+    assert tuple(both.shape) == (16, 4, 16, 16)
+    assert (both - single).abs().max().item() < 5e-3 * single.abs().max().item()
+    for ln in lines:
+        assert os.path.isfile(str(tmp_path / "two" / ("_".join(os.path.splitext(n)[0] for n in ln.split()) + ".pt")))

@@ -8,7 +8,7 @@ TAG=${1:-r1}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench --output-format csv -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-block-skip --no-content-cache > $OUT/bench_under_rocprof.json 2> $OUT/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench --output-format csv -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-block-skip --no-content-cache --no-feature-scale --no-sweep --no-default-queues > $OUT/bench_under_rocprof.json 2> $OUT/bench.err
 P=/root/repo/tools/prof_attn.py
 timeout -s KILL 90 rocprofv3 --kernel-trace --stats -d $OUT/attn -o attn --output-format csv -- python3 $P 4096 40 1 20 > $OUT/attn.txt 2>&1
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAIT_ANY -d $OUT/p1 --output-format csv -- python3 $P 4096 40 1 3 > /dev/null 2>&1

@@ -40,8 +40,23 @@ for i, nm in enumerate(names):
 print("  wg lifetime            mean %.2f us  max %.2f" % (((t[:, 5] - t[:, 0]) / 100).mean(), ((t[:, 5] - t[:, 0]) / 100).max()))
 print("  entry time spread      first %.2f us last %.2f us" % (0.0, (t[:, 0].max() - t0) / 100))
 print("  end time spread        first %.2f us last %.2f us" % ((t[:, 5].min() - t0) / 100, (t[:, 5].max() - t0) / 100))
+# all segments of a workgroup: time inside the stage loops (pipelined steady loop + tail stages) against its lifetime
+seg_ok = raw[:, :, 5] > 0
+loop_us = (((raw[:, :, 4] - raw[:, :, 2]) * seg_ok).sum(axis=1)) / 100
+life_us = (t[:, 5] - t[:, 0]) / 100
+span_us = (t[:, 5].max() - t0) / 100
+summary = {"N": N, "d": d, "B": B, "call": "plain" if plain else "injected", "workgroups": int(len(t)), "kernel_span_us": float(span_us),
+           "stage_loops_us_per_workgroup": float(loop_us.mean()), "lifetime_us_per_workgroup": float(life_us.mean()),
+           "fixed_cost_us_per_workgroup": float((life_us - loop_us).mean()),
+           "steady_loop_frac": float(loop_us.mean() / span_us), "segments_per_workgroup": float(nseg.mean())}
 steady = (t[:, 3] - t[:, 2]) * 10e-9
 ok = steady > 0
+summary["shader_clock_GHz_in_the_loop"] = float((cyc[ok] / steady[ok]).mean() / 1e9)
+if os.environ.get("SID_DIAG_JSON"):
+    import json
+    with open(os.environ["SID_DIAG_JSON"], "w") as jf:
+        json.dump(summary, jf)
+print("  summary", summary)
 print("  shader clock in the steady loop: %.2f GHz (mean over workgroups), cycles per workgroup %.0f" % ((cyc[ok] / steady[ok]).mean() / 1e9, cyc[ok].mean()))
 # per-run breakdown (the mapping of the kernel: ids equal mod 8 share a (head, run) group)
 W = int(os.environ.get("SID_TUNE_W", "0"))

@@ -60,6 +60,10 @@ t_call = graph_time(call)
 t_flash = graph_time(lambda: call(0x20))
 if base_flags & 1:
     call(); print("skip counters", ops.skip_counts(xq, H, compute, packed=True), end=" ")
+print("N=%d d=%d B=%d %s: call %.1f us (%.0f TF/s = %.1f%% of 2.5 PF) | flash stage alone %.1f us (%.1f%%)" % (
+    N, d, B, compute, t_call, fl / t_call / 1e6, fl / t_call / 2.5e9 * 100, t_flash, fl / t_flash / 2.5e9 * 100))
+if os.environ.get("SID_TUNE_W") or os.environ.get("SID_TUNE_KS") or os.environ.get("PROF_NO_CACHED"):
+    sys.exit(0)                             # (a content partial is one run per head: not under a forced decomposition)
 # the same call with the content block taken from a partial computed once (sid_injected_attn_fwd_cached)
 partial = ops.content_partial(q_cnt, kv[2], d ** -0.5, H)
 cached = lambda flags=0: ops.injected_attention_cached(xq, q_cnt, kv[0], kv[1], partial, m, 0.5, 1.5, d ** -0.5, H, out=out,
@@ -72,5 +76,3 @@ t_cflash = graph_time(lambda: cached(0x20))
 os.environ.pop("SID_TUNE_W", None)
 t_partial = graph_time(lambda: ops.content_partial(q_cnt, kv[2], d ** -0.5, H))
 print("cached content block: call %.1f us | flash stage %.1f us | making the partial %.1f us" % (t_cached, t_cflash, t_partial))
-print("N=%d d=%d B=%d %s: call %.1f us (%.0f TF/s = %.1f%% of 2.5 PF) | flash stage alone %.1f us (%.1f%%)" % (
-    N, d, B, compute, t_call, fl / t_call / 1e6, fl / t_call / 2.5e9 * 100, t_flash, fl / t_flash / 2.5e9 * 100))

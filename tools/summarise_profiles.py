@@ -11,7 +11,7 @@ def kstats(path, skip=None):
                           capture_output=True, text=True).stdout
 
 with open(os.path.join(dst, tag + "_bench_kernel_stats.txt"), "w") as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-block-skip --no-content-cache\n")
+    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-block-skip --no-content-cache --no-feature-scale --no-sweep --no-default-queues\n")
     f.write("(4 images: 1 warm-up + 3 timed; the torch normal_ kernels that create the synthetic workload are left out)\n\n")
     f.write(kstats(os.path.join(src, "bench", "bench_kernel_stats.csv"), "at::native"))
     f.write("\nbench line printed under the profiler:\n" + open(os.path.join(src, "bench_under_rocprof.json")).read())
