@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from style_transfer_amd import ops
 N, d, B, reps = (int(sys.argv[i]) if len(sys.argv) > i else v for i, v in ((1, 4096), (2, 40), (3, 1), (4, 10)))
-compute = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+compute = sys.argv[5] if len(sys.argv) > 5 else "f16"      # the package default
 H = 8
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
