@@ -382,10 +382,26 @@ __device__ __forceinline__ void process_stage(const u32x4* L, int lane, int hh, 
 // group so the compiler keeps the interleave.  The pipeline runs across stage boundaries: the logits
 // of the next stage's first unit are computed in the last slot of a stage (after the barrier that
 // publishes that stage), and the P.V of a stage's last unit runs in the first slot of the next.
-enum { kOpExp, kOpCvt, kOpMax, kOpMin, kOpUpdMax, kOpUpdMin };
+enum { kOpExp, kOpCvt, kOpMax, kOpMin };
 struct SoftmaxOps { int n; int kind[64]; int arg[64]; };
-// The vector ops of one unit in issue order: per pair of logits two exponentials, a step of the max
-// OR min tree, and the bf16 packing of the previous pair.  The pipelined loop tracks exactly one
+// One instruction each, whatever the compiler knows about the operands: written with fmaxf / fminf the
+// tree on MFMA results gets canonicalising v_max x, x in front (the results might be signalling NaNs for all
+// the compiler knows), and every extra vector instruction of the steady loop costs the issue port four cycles.
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float min3_f32(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// The vector ops of one unit in issue order: per pair of logits two exponentials, a step of the running max
+// OR min (one three-operand instruction that folds the pair into the segment's running extreme, which
+// lives in the accumulator's own coordinates until the loop ends: 32 vector instructions per unit, none
+// besides the exponentials, the extreme and the packing), and the bf16 packing of the previous pair.
+// The pipelined loop tracks exactly one
 // extreme of the logits per segment, the one the mask bias needs from it (the largest raw q.k of a
 // style block, the smallest content logit): overflow is caught from the row sums instead of from the
 // row maximum, and the merge takes its reference from the sums as well.
@@ -399,7 +415,6 @@ constexpr SoftmaxOps softmax_ops(bool track_min) {
         if (g > 0) { t.kind[n] = kOpCvt; t.arg[n++] = g - 1; }
     }
     t.kind[n] = kOpCvt; t.arg[n++] = 7;
-    t.kind[n] = track_min ? kOpUpdMin : kOpUpdMax; t.arg[n++] = 0;
     t.n = n;
     return t;
 }
@@ -420,10 +435,11 @@ struct StagePipe {
     static constexpr int NVS = QT == 1 ? 2 : 1;
     Frags<2 * DVB, false> vf[NVS];     // V^T fragments of the tile(s) of the running P.V
     float e[16];
-    float tmax, tmin;
+    float ext[QT];                     // running extreme of every query tile's logits, as the MFMA leaves them
+                                       // (with the reference already subtracted in the shifted mode)
 
     template <int I>
-    __device__ __forceinline__ void op(const f32x16& Sx, bf16x8 (&Px)[2], RowState& r) {
+    __device__ __forceinline__ void op(const f32x16& Sx, bf16x8 (&Px)[2], RowState& r, float& x) {
         constexpr int kind = T.kind[I], a = T.arg[I];
         if constexpr (kind == kOpExp) {
             e[a] = __builtin_amdgcn_exp2f(MODE == kShifted ? Sx[a] : Sx[a] - r.m2);
@@ -431,17 +447,19 @@ struct StagePipe {
             Px[a / 4][2 * (a % 4)] = (__bf16)e[2 * a];
             Px[a / 4][2 * (a % 4) + 1] = (__bf16)e[2 * a + 1];
         } else if constexpr (kind == kOpMax) {
-            if constexpr (a == 0) tmax = fmaxf(fmaxf(Sx[0], Sx[1]), Sx[2]);
-            else if constexpr (a < 7) tmax = fmaxf(fmaxf(tmax, Sx[2 * a + 1]), Sx[2 * a + 2]);
-            else tmax = fmaxf(tmax, Sx[15]);
-        } else if constexpr (kind == kOpMin) {
-            if constexpr (a == 0) tmin = fminf(fminf(Sx[0], Sx[1]), Sx[2]);
-            else if constexpr (a < 7) tmin = fminf(fminf(tmin, Sx[2 * a + 1]), Sx[2 * a + 2]);
-            else tmin = fminf(tmin, Sx[15]);
-        } else if constexpr (kind == kOpUpdMax) {
-            r.smax = fmaxf(r.smax, MODE == kShifted ? tmax + r.m2 : tmax);     // unshifted coordinates
+            x = max3_f32(x, Sx[2 * a], Sx[2 * a + 1]);
         } else {
-            r.smin = fminf(r.smin, MODE == kShifted ? tmin + r.m2 : tmin);
+            x = min3_f32(x, Sx[2 * a], Sx[2 * a + 1]);
+        }
+    }
+
+    // After the loop: the running extremes go back to the row state, in unshifted coordinates.
+    __device__ __forceinline__ void fold(RowState (&rs)[QT]) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float x = MODE == kShifted ? ext[t] + rs[t].m2 : ext[t];
+            if (TRACK_MIN) rs[t].smin = fminf(rs[t].smin, x);
+            else rs[t].smax = fmaxf(rs[t].smax, x);
         }
     }
 
@@ -456,6 +474,8 @@ struct StagePipe {
 
     // Before the first slot: the logits of the stage's first unit; a zero P.V stands in for unit -1.
     __device__ __forceinline__ void begin(const u32x4* L, int lane, const QF (&qf)[QT]) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) ext[t] = TRACK_MIN ? SID_INF : -SID_INF;
         load_k(L, 0, lane);
 #pragma unroll
         for (int i = 0; i < 2 * DVB; ++i)
@@ -526,7 +546,7 @@ struct StagePipe {
                 O[tp][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[vs].hi[DVB + b], Pk[sn][1], O[tp][b], 0, 0, 0);
                 if constexpr (b == DVB - 1) reload_v(1);
             }
-            static_for<m * T.n / NM, (m + 1) * T.n / NM>([&](auto ic) { op<decltype(ic)::value>(S[sc], Pk[sc], rs[t]); });
+            static_for<m * T.n / NM, (m + 1) * T.n / NM>([&](auto ic) { op<decltype(ic)::value>(S[sc], Pk[sc], rs[t], ext[t]); });
             __builtin_amdgcn_sched_barrier(0);
         });
     }
@@ -856,7 +876,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashPa
                 }
                 if (wave_live) pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
             }
-            if (wave_live) pipe.finish(O);
+            if (wave_live) { pipe.finish(O); pipe.fold(rs); }
             nissued = max(nissued, min(slen, it1 + NB));
         }
     };
