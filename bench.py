@@ -917,6 +917,7 @@ def run_rank(args, world, rank, local):
 
     if rank == 0 and args.headline_only:
         print(json.dumps({"value": world * args.steps / elapsed, "unit": "imgs/s", "n_gpus": world, "steps": args.steps,
+                          "ms_per_step": 1e3 * elapsed / args.steps,
                           "hardware_queues_per_process": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                           "images_in_flight": n_lanes, "compute": args.compute}), flush=True)
     elif rank == 0:

@@ -14,7 +14,7 @@ full = bench.run_image
 def variant(extra_flags=0, plain=True, hf=True, inj=(True, True), plain_keep=lambda N: True):
     state = {"calls": 0}
 
-    def run(w, compute, flags=0):
+    def run(w, compute, flags=0, cached=False):
         # the eager call bench.py makes per lane before capture runs everything once, so that the
         # workspaces hold valid packed images and partials for the stage-subset replays
         if not torch.cuda.is_current_stream_capturing():
@@ -41,7 +41,7 @@ def variant(extra_flags=0, plain=True, hf=True, inj=(True, True), plain_keep=lam
     return run
 
 
-lanes = os.environ.get("ABLATE_LANES", "3")
+lanes = os.environ.get("ABLATE_LANES", "4")
 CASES = [("everything", full), ("no merge stage", variant(0x30)), ("no pack stage", variant(0x60)),
          ("flash stage only", variant(0x20)), ("no plain attentions", variant(0, plain=False)),
          ("no plain N=4096", variant(0, plain_keep=lambda N: N != 4096)),
@@ -49,12 +49,22 @@ CASES = [("everything", full), ("no merge stage", variant(0x30)), ("no pack stag
          ("no plain N<=256", variant(0, plain_keep=lambda N: N > 256)),
          ("no HF sums", variant(0, hf=False)), ("only N=4096 injected", variant(0, plain=False, hf=False, inj=(True, False))),
          ("only N=4096 injected, flash only", variant(0x20, plain=False, hf=False, inj=(True, False)))]
-lanes = os.environ.get("ABLATE_LANES", "3")
 if os.environ.get("ABLATE_NO_THROUGHPUT_FLAG") == "1":
     ops.FLAG_THROUGHPUT = 0
 if os.environ.get("ABLATE_CASES"):
     CASES = [c for i, c in enumerate(CASES) if str(i) in os.environ["ABLATE_CASES"].split(",")]
-sys.argv = [sys.argv[0], "--no-cpu-baseline", "--no-e2e", "--steps", os.environ.get("ABLATE_STEPS", "45"), "--warmup", "15", "--in-flight", lanes]
+else:
+    # one fresh process per case: the runtime spreads a process's streams over its hardware queues in creation
+    # order, and the lane streams of a second bench.main() in one process can land on shared queues (lanes that
+    # share a queue run one after the other), which would be measured as part of the case
+    import subprocess
+    for i in range(len(CASES)):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, ABLATE_CASES=str(i)),
+                           capture_output=True, text=True)
+        sys.stdout.write(r.stdout if r.returncode == 0 else "case %d failed: %s\n" % (i, r.stderr[-300:]))
+        sys.stdout.flush()
+    sys.exit(0)
+sys.argv = [sys.argv[0], "--headline-only", "--steps", os.environ.get("ABLATE_STEPS", "45"), "--warmup", "15", "--in-flight", lanes]
 for name, fn in CASES:
     bench.run_image = fn
     buf = io.StringIO()
