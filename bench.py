@@ -658,7 +658,7 @@ def e2e_record(dev, compute, store):
                     "eager_host_unet: one image at a time launched kernel by kernel; VAE and text encoder not run"}
 
 
-def sweep_record(dev, compute):
+def sweep_record(dev, compute, n_cnt=2, n_char=2, n_back=2, reference_lines=3):
     """configs[3] in small: the run.py loop (style_transfer_amd.run.run_lines: loader, masked AdaIN, merge, 49
     graphed evaluations per line) over 8 lines = 2 contents x 2 character styles x 2 background styles, whose
     six SD-v1-sized feature files (3.54 GB pickles written by save_feature_file) sit in tmpfs; imgs/s
@@ -671,8 +671,9 @@ def sweep_record(dev, compute):
     from style_transfer_amd.sampler import DDIMSampler
     base_dir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     free = shutil.disk_usage(base_dir).free
-    if free < 48 << 30:
-        return {"skipped": "%s has %.0f GB free; the sweep needs 48" % (base_dir, free / 1e9)}
+    need = int((n_cnt + n_char + n_back) * 3.6e9 * 1.6) + (8 << 30)          # pickles + side-cars + slack
+    if free < need:
+        return {"skipped": "%s has %.0f GB free; the sweep needs %.0f" % (base_dir, free / 1e9, need / 1e9)}
     root = tempfile.mkdtemp(prefix="sid_sweep_", dir=base_dir)
     try:
         data, pre = os.path.join(root, "data"), os.path.join(root, "pre")
@@ -694,7 +695,8 @@ def sweep_record(dev, compute):
             return out
 
         t0 = time.perf_counter()
-        names = {"cnt": ["c1", "c2"], "sty/char": ["a1", "a2"], "sty/back": ["b1", "b2"]}
+        names = {"cnt": ["c%d" % i for i in range(1, n_cnt + 1)], "sty/char": ["a%d" % i for i in range(1, n_char + 1)],
+                 "sty/back": ["b%d" % i for i in range(1, n_back + 1)]}
         for sub, lst in names.items():
             for i, n in enumerate(lst):
                 open(os.path.join(data, sub, n + ".png"), "wb").write(b"x")
@@ -715,10 +717,12 @@ def sweep_record(dev, compute):
             uc = torch.zeros(1, 77, 768, device=dev)
         triples = cli.list_triples(data)
         common = ["--data_root", data, "--precomputed", pre, "--output_path", os.path.join(root, "out"), "--gamma", str(GAMMA),
-                  "--T", str(TEMP), "--compute", compute, "--graph_unet"]
+                  "--T", str(TEMP), "--compute", compute, "--graph_unet"] + (["--progress"] if "--progress" in sys.argv else [])
         os.makedirs(os.path.join(root, "out"))
 
         def run(extra, lines_idx):
+            sys.stderr.write("sweep: %d lines, %s\n" % (len(lines_idx), " ".join(extra)))      # (a long silent run looks hung)
+            sys.stderr.flush()
             opt = cli.build_parser().parse_args(common + extra)
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -731,14 +735,14 @@ def sweep_record(dev, compute):
                     "sampler_waited_s": st["wait_seconds"]}
 
         every = list(range(len(triples)))
-        rec = {"what": "run.py loop over 8 lines (2 contents x 2 character x 2 background styles), six 3.54 GB feature pickles in "
-                       "%s, one image at a time, every evaluation a HIP graph; imgs/s include reading, uploading and packing the "
-                       "feature files" % base_dir,
+        rec = {"what": "run.py loop over %d lines (%d contents x %d character x %d background styles), %d feature pickles of 3.54 GB in "
+                       "%s, one image at a time unless stated, every evaluation a HIP graph; imgs/s include reading, uploading and "
+                       "packing the feature files" % (len(lines), n_cnt, n_char, n_back, n_cnt + n_char + n_back, base_dir),
                "pickle_GB": pkl_bytes / 1e9, "files_written_s": t_write}
         run(["--no_prefetch", "--sidecar", "off", "--store_cache_gb", "0"], every[:1])       # warm-up: graph capture, conv kernels
         # the reference's order: every line reads its three pickles when its turn comes, nothing is kept (run_ori.py:168-222)
-        rec["reference_order"] = run(["--no_prefetch", "--sidecar", "off", "--store_cache_gb", "0"], every[:3])
-        rec["reference_order"]["note"] = "first 3 lines only (every line costs the same: 3 pickles)"
+        rec["reference_order"] = run(["--no_prefetch", "--sidecar", "off", "--store_cache_gb", "0"], every[:reference_lines])
+        rec["reference_order"]["note"] = "first %d lines only (every line costs the same: 3 pickles)" % reference_lines
         rec["prefetch_lru_pickles"] = run(["--sidecar", "write"], every)                     # also writes the side-cars
         rec["prefetch_lru_sidecars"] = run(["--sidecar", "use"], every)
         rec["prefetch_lru_sidecars_4_lanes"] = run(["--sidecar", "use", "--lanes", "4"], every)

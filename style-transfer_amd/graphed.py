@@ -57,6 +57,10 @@ class GraphedUNet:
         return (tuple(x.shape), x.dtype, None if context is None else tuple(context.shape), cnt, cfg, keys)
 
     def _capture(self, x, timesteps, context, feats):
+        with ops.capture_lock:           # the feature loader's thread stays off the GPU meanwhile
+            self._capture_locked(x, timesteps, context, feats)
+
+    def _capture_locked(self, x, timesteps, context, feats):
         self.x, self.t = x.clone(), timesteps.clone()
         self.ctx = None if context is None else context.clone()
         self.slots = None

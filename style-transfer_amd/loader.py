@@ -6,7 +6,8 @@ loader takes the files off the sampling path:
 
   * a worker thread reads the NEXT triple's files while the current one samples: file -> HBM on a side
     stream (a side-car through two pinned staging slots) -> `sid_pack_kv` on that stream; the sampling
-    stream only waits for the event that marks a file ready;
+    stream only waits for the event that marks a file ready.  The worker touches the GPU one list entry at
+    a time under `ops.capture_lock`, which the sampling thread holds while it captures a HIP graph;
   * every loaded (and packed) list stays in HBM under an LRU bound, keyed by file: a sweep that pairs one
     style with many contents (or one content with many style pairs) reads each file once;
   * a packed side-car (`{base}_cnt.sidpack` / `{base}_sty.sidpack`, feature_store.write_sidecar) holds what
@@ -133,9 +134,10 @@ class FeatureLoader:
     # ---- one file -----------------------------------------------------------------------------
     def _ensure_stream(self):
         if self.device.type == "cuda" and self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
-            # two pinned staging slots: slot k is refilled while slot k^1 is still on its way to HBM
-            self._staging = [[torch.empty(self._staging_bytes, dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
+            with ops.capture_lock:
+                self._stream = torch.cuda.Stream(device=self.device)
+                # two pinned staging slots: slot k is refilled while slot k^1 is still on its way to HBM
+                self._staging = [[torch.empty(self._staging_bytes, dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
             self._slot = 0
 
     def _load(self, key, two_styles):
@@ -166,16 +168,21 @@ class FeatureLoader:
                 feats, blocks, nfile = self._read_pickle(pkl, role, want_packed)
             event = None
             if self._stream is not None:
-                with torch.cuda.stream(self._stream):
-                    if want_packed and route == "pkl":
-                        fs.pack_feature_list(feats, self.heads, self.compute, self.T)
-                    if want_packed and role == "cnt" and self.cache_content:
-                        fs.cache_content_blocks(feats, self.heads)
+                # entry by entry, each under the capture lock: a graph capture on the sampling thread waits for
+                # one entry's launches at most, and this thread stays off the GPU while it captures
+                for e in feats:
+                    with ops.capture_lock, torch.cuda.stream(self._stream):
+                        if want_packed and route == "pkl":
+                            fs.pack_feature_list([e], self.heads, self.compute, self.T)
+                        if want_packed and role == "cnt" and self.cache_content:
+                            fs.cache_content_blocks([e], self.heads)
+                with ops.capture_lock:
                     event = torch.cuda.Event()
                     event.record(self._stream)
                 if want_packed and route == "pkl" and self.sidecar == "write":
-                    self._stream.synchronize()
-                    fs.write_sidecar(side, feats, role, self.heads, self.compute, pkl)
+                    with ops.capture_lock:
+                        self._stream.synchronize()
+                        fs.write_sidecar(side, feats, role, self.heads, self.compute, pkl)
             blocks = self._live_blocks(feats)
             hbm = sum(b.untyped_storage().nbytes() for b in blocks)
         return _Loaded(feats, blocks or [], event, hbm, nfile, time.perf_counter() - t0, route)
@@ -210,12 +217,14 @@ class FeatureLoader:
             return flat
         if total > self._staging_bytes:
             self._staging_bytes = (total + (16 << 20)) // (16 << 20) * (16 << 20)
-            self._stream.synchronize()
-            self._staging = [[torch.empty(self._staging_bytes, dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
+            with ops.capture_lock:
+                self._stream.synchronize()
+                self._staging = [[torch.empty(self._staging_bytes, dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
         slot = self._staging[self._slot]
         self._slot ^= 1
         if slot[1] is not None:
-            slot[1].synchronize()                    # the slot's previous upload has left it
+            with ops.capture_lock:
+                slot[1].synchronize()                # the slot's previous upload has left it
         host = slot[0]
         for off, src in pieces:
             if torch.is_tensor(src):
@@ -226,7 +235,7 @@ class FeatureLoader:
                 got = f.readinto(memoryview(host[off:off + n].numpy()))
                 if got != n:
                     raise OSError("short read: %d of %d bytes" % (got, n))
-        with torch.cuda.stream(self._stream):
+        with ops.capture_lock, torch.cuda.stream(self._stream):
             flat = torch.empty(total, dtype=torch.uint8, device=self.device)
             flat.copy_(host[:total], non_blocking=True)
             slot[1] = torch.cuda.Event()
@@ -249,25 +258,29 @@ class FeatureLoader:
         for k, v in entry.items():
             if torch.is_tensor(v) and v.is_floating_point() and k != "z_enc" and v.dtype != self.dtype:
                 if self._stream is not None:
-                    with torch.cuda.stream(self._stream):
+                    with ops.capture_lock, torch.cuda.stream(self._stream):
                         entry[k] = v.to(self.dtype)
                 else:
                     entry[k] = v.to(self.dtype)
 
     def _read_pickle(self, pkl, role, want_packed):
-        """The reference's file through the allow-list unpickler, every storage decoded straight onto the
-        device (measured faster than a detour through pinned staging: the unpickler's own copy is the cost).
-        A packed style list drops its queries at once (nothing reads them); keys and values are freed when
-        they have been packed."""
-        if self._stream is not None:
-            with torch.cuda.stream(self._stream):
-                feats = fs.load_feature_file(pkl, self.device, None)
-        else:
-            feats = fs.load_feature_file(pkl, self.device, None)
-        for e in feats:
-            if want_packed and role == "sty":
-                for k in [k for k in e if k.endswith("_self_attn_q")]:
-                    del e[k]
+        """The reference's file through the allow-list unpickler onto the host (no GPU call: this part runs
+        whatever the sampling thread does), then entry by entry into HBM.  A packed style list never uploads its
+        queries (nothing reads them); keys and values are freed when they have been packed."""
+        host = fs.load_feature_file(pkl, "cpu", None)
+        feats = []
+        for e in host:
+            out = {}
+            keep = [(k, v) for k, v in e.items()
+                    if not (want_packed and role == "sty" and torch.is_tensor(v) and k.endswith("_self_attn_q"))]
+            if self._stream is not None:
+                with ops.capture_lock, torch.cuda.stream(self._stream):
+                    for k, v in keep:
+                        out[k] = v.to(self.device).contiguous() if torch.is_tensor(v) else v
+            else:
+                for k, v in keep:
+                    out[k] = v.to(self.device).contiguous() if torch.is_tensor(v) else v
             if self.dtype is not None:
-                self._cast(e)
+                self._cast(out)
+            feats.append(out)
         return feats, None, os.path.getsize(pkl)

@@ -8,11 +8,21 @@ the other two.  The long-sequence kernels refuse "f16" for logit scales outside 
 PyTorch is used for device memory and streams only; all arithmetic of the path happens in
 libsid.so.  Every function raises if the library is missing or rejects the call.
 """
+import threading
+
 import torch
 
 from . import lib as _lib
 
 _workspaces = {}
+
+# Held by a thread while it captures a HIP graph (graphed.GraphedUNet) and, in short pieces, by the feature
+# loader's worker thread around its GPU calls.  The two must not overlap: with the capturing thread in the
+# thread-local capture mode the runtime accepts another thread's allocations and copies during the capture, but
+# a blocking copy from pageable memory that races with it fails now and then with "operation not permitted when
+# stream is capturing" (measured: once in a few thousand copies), and a failed call invalidates nothing but
+# itself, so the loader would lose a file.
+capture_lock = threading.RLock()
 
 
 def _dtype_code(t):

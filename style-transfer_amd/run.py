@@ -74,6 +74,7 @@ def build_parser():
     p.add_argument('--lanes', type=int, default=1,
                    help="images in flight on one GPU: each lane replays its own HIP graph of the UNet evaluation on its own stream "
                         "(implies --graph_unet; lines whose content has a residual file are stylised one at a time)")
+    p.add_argument('--progress', action='store_true', help="one line on stderr per finished batch of lines")
     p.add_argument('--no_prefetch', action='store_true', help="read the feature files of a line only when its turn comes (the reference's order)")
     p.add_argument('--sidecar', default='use', choices=['off', 'use', 'write'],
                    help="packed side-car files beside the pickles ({base}_cnt.sidpack / {base}_sty.sidpack): 'use' reads one when it "
@@ -303,6 +304,9 @@ def run_lines(opt, model, sampler, triples, mine, uc, device):
                 for j, z in zip(batch, zs):
                     save(mine[j], z)
             del stores
+            if getattr(opt, "progress", False):
+                sys.stderr.write("lines done: %d of %d\n" % (batch[-1] + 1, len(mine)))
+                sys.stderr.flush()
     loader.close()
     return latents, dict(loader.stats)
 

@@ -300,3 +300,38 @@ def test_sweep_of_16_lines_over_two_ranks_with_lanes(tmp_path):
     assert (both - single).abs().max().item() < 5e-3 * single.abs().max().item()
     for ln in lines:
         assert os.path.isfile(str(tmp_path / "two" / ("_".join(os.path.splitext(n)[0] for n in ln.split()) + ".pt")))
+
+
+def test_loader_and_graph_capture_take_turns(tmp_path):
+    """The loader's thread reads, uploads and packs while the sampling thread captures UNet evaluations over and
+    over.  Left to overlap, a blocking copy of the loader fails now and then with "operation not permitted when
+    stream is capturing" (once in a few thousand copies, whatever capture mode the threads are in), so the two
+    take turns through ops.capture_lock: GraphedUNet holds it while it captures, the loader takes it one list
+    entry at a time.  Every load must succeed and hand out the bytes a plain load gives."""
+    from style_transfer_amd import unet as U
+    from style_transfer_amd.graphed import GraphedUNet
+    root, pre = make_root(tmp_path, ["c1.jpg a.png b.png"])
+    want = fs.FeatureStore.load(str(pre), "c1", "a", "b", "cuda:0").pack(8, "f16", T=1.5)
+    model = U.UNetModel(**case()["cfg"]).eval().to("cuda:0")
+    model.set_content_name(str(root / "cnt" / "nomask.jpg"))
+    x, t = torch.randn(1, 4, 16, 16, device="cuda:0"), torch.tensor([481], device="cuda:0")
+    ctx = torch.randn(1, 77, 768, device="cuda:0")
+    ld = FeatureLoader(str(pre), "cuda:0", heads=8, compute="f16", T=1.5, sidecar="off", prefetch=True, cache_bytes=0)
+    loads = 0
+    with torch.no_grad():
+        ld.request(("c1", "a", "b"))
+        import time
+        for i in range(40):
+            GraphedUNet(model)(x, t, ctx)                        # warm-up + capture, under the lock
+            time.sleep(0.2)                                      # (the sampling of an image: the loader's turn)
+            if all(f.done() for f in ld._pending.values()):
+                got = ld.get(("c1", "a", "b"))                   # raises if any call of the load failed
+                loads += 1
+                if loads == 1:
+                    torch.cuda.synchronize()
+                    same_store(got, want)
+                del got
+                ld.request(("c1", "a", "b"))                     # cache_bytes = 0: the files are read again
+    ld.get(("c1", "a", "b"))
+    ld.close()
+    assert loads >= 2 and ld.stats["files"] == 3 * (loads + 1)
