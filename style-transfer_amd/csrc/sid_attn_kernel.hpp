@@ -135,7 +135,10 @@ constexpr size_t tile_bytes(int DKS, int DVB, bool x3) { return (size_t)(DKS + 2
 // tiles per LDS stage: two, unless two double-buffered stages exceed what lets two workgroups share a CU
 constexpr int stage_tiles(int DKS, int DVB, bool x3) { return 2 * 2 * tile_bytes(DKS, DVB, x3) <= 80 * 1024 ? 2 : 1; }
 // query tiles per wave: two where the accumulators of both fit the 256-register budget
-constexpr int query_tiles(int DKS, int DVB, bool x3) { return (!x3 && DKS <= 3 && DVB <= 2) ? 2 : 1; }
+#ifndef SID_WIDE_QT
+#define SID_WIDE_QT 2
+#endif
+constexpr int query_tiles(int DKS, int DVB, bool x3) { return (!x3 && DKS <= 3 && DVB <= 2) ? SID_WIDE_QT : 1; }
 
 // Registers the software-pipelined loop keeps live (accumulators, two sets of logits and packed
 // probabilities, Q, K and V fragments); the kernel uses it where they leave room in the 256-register
@@ -146,7 +149,7 @@ constexpr int pipeline_registers(int DKS, int DVB, int QT) {
 
 // the software-pipelined loop is used by this instance
 constexpr bool pipelined(int DKS, int DVB, bool x3) {
-    return !x3 && stage_tiles(DKS, DVB, x3) % 2 == 0 && pipeline_registers(DKS, DVB, query_tiles(DKS, DVB, x3)) <= 190;
+    return !x3 && stage_tiles(DKS, DVB, x3) % 2 == 0 && pipeline_registers(DKS, DVB, query_tiles(DKS, DVB, x3)) <= (SID_WIDE_QT > 2 ? 440 : 190);
 }
 // LDS stage buffers (a ring: stage s lives in buffer s % ring_stages, and a stage is requested
 // ring_stages - 1 stages of compute before it is used).  Two: deeper rings were measured (three and
@@ -582,7 +585,7 @@ __device__ __forceinline__ void wait_direct_loads() { asm volatile("s_waitcnt vm
 // SKIP: block skipping (SID_FLAG_BLOCK_SKIP); instances of their own, so that calls without the flag run
 // exactly the code they ran before it existed.
 template <int DKS, int DVB, int KVS, bool X3, int QT, int NW, bool SHIFT, bool QK16, bool SKIP = false>
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) flash_kernel(FlashParams P) {
+__global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_kernel(FlashParams P) {
     static_assert(!(SKIP && X3), "block skipping reads the f32 statistics of the bf16 / f16 kernels");
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     constexpr int KU = KVS * DKS * 64;        // u32x4 per stage: K image

@@ -12,7 +12,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define MFMA32(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MFMA16(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 
-enum { ADD = 0, EXP = 1, CVT = 2, MAX3 = 3, PKADD = 4, MOV = 5, DSREAD = 6, DSREAD64 = 7 };
+enum { ADD = 0, EXP = 1, CVT = 2, MAX3 = 3, PKADD = 4, MOV = 5, DSREAD = 6, DSREAD64 = 7,
+       EXP16 = 8, EXP16HI = 9, EXPLEG = 10, CVTRTZ = 11, LDEXP = 12, PKMUL16 = 13 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
@@ -23,6 +24,14 @@ __device__ __forceinline__ void vop(float& x, float y, float z) {
     if (OP == CVT) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));
     if (OP == MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
     if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(y));
+    // half-precision exponentials (low half; high half in place through SDWA), the legacy f32 form, and what a
+    // half-precision softmax would need around them
+    if (OP == EXP16) asm volatile("v_exp_f16 %0, %0" : "+v"(x));
+    if (OP == EXP16HI) asm volatile("v_exp_f16_sdwa %0, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(x));
+    if (OP == EXPLEG) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(x));
+    if (OP == CVTRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));
+    if (OP == LDEXP) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+    if (OP == PKMUL16) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(x) : "v"(y));
 }
 
 // MF: 0 none, 1 = 32x32x16 (8 passes), 2 = 16x16x32 (4 passes... per its own shape)
@@ -112,12 +121,26 @@ void sweep(const char* name) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     (void)hipMalloc(&g_out, 256 * 512 * sizeof(float));
     // calibrate the clock: back-to-back 32x32x16 MFMAs take 32 cycles each
     for (int i = 0; i < 3; ++i) run<1, 0, ADD>(256);
     g_ghz = 32.0 / run<1, 0, ADD>(256);
     printf("clock from MFMA calibration: %.2f GHz\n", g_ghz);
+    if (argc > 1) {   // any argument: only the half-precision exponential survey
+        sweep<0, EXP>("no mfma + exp_f32");
+        sweep<0, EXP16>("no mfma + exp_f16");
+        sweep<0, EXP16HI>("no mfma + exp_f16 hi");
+        sweep<0, EXPLEG>("no mfma + exp_legacy");
+        sweep<0, CVTRTZ>("no mfma + cvt_pkrtz");
+        sweep<0, LDEXP>("no mfma + ldexp");
+        sweep<0, PKMUL16>("no mfma + pk_mul_f16");
+        sweep<1, EXP>("mfma32 + exp_f32");
+        sweep<1, EXP16>("mfma32 + exp_f16");
+        sweep<1, EXP16HI>("mfma32 + exp_f16 hi");
+        sweep<1, EXPLEG>("mfma32 + exp_legacy");
+        return 0;
+    }
     sweep<0, DSREAD>("no mfma + ds_read_b128");
     sweep<1, DSREAD>("mfma32 + ds_read_b128");
     sweep<0, DSREAD64>("no mfma + ds_read_b64");
