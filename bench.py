@@ -327,11 +327,21 @@ def block_skip_record(dev, compute):
             t_on = events_per_call(lambda: call(ops.FLAG_BLOCK_SKIP), reps)
             call(ops.FLAG_BLOCK_SKIP)
             counts = ops.skip_counts(xq, HEADS, mode, packed=True)
+            # the same call with the content block taken from a cached partial (two style blocks in the call)
+            partial = ops.content_partial(q_cnt, kv[2], d ** -0.5, HEADS)
+            ccall = lambda fl: ops.injected_attention_cached(xq, q_cnt, kv[0], kv[1], partial, mask, GAMMA, TEMP, d ** -0.5,
+                                                             HEADS, out=out, flags=fl)
+            tc_off = events_per_call(lambda: ccall(0), reps)
+            tc_on = events_per_call(lambda: ccall(ops.FLAG_BLOCK_SKIP), reps)
+            ccounts = ops.skip_counts(xq, HEADS, mode, packed="cached")
             rec["cases"].append({"B": B, "feature_sigma": sigma, "call_ms_flag_off": t_off * 1e3, "call_ms_flag_on": t_on * 1e3,
                                  "time_ratio": t_on / t_off,
                                  "query_groups": counts[3], "groups_with_a_dead_style_block": counts[0],
-                                 "content_segments_logits_only": counts[1], "of_those_redone_in_full": counts[2]})
-            del xq, q_cnt, kv, out
+                                 "content_segments_logits_only": counts[1], "of_those_redone_in_full": counts[2],
+                                 "content_cached": {"call_ms_flag_off": tc_off * 1e3, "call_ms_flag_on": tc_on * 1e3,
+                                                    "time_ratio": tc_on / tc_off,
+                                                    "groups_with_a_dead_style_block": ccounts[0]}})
+            del xq, q_cnt, kv, out, partial
             torch.cuda.empty_cache()
     # the whole hot path of an image, images in flight as in `value`, at feature-sized logits (x2 and x3): the headline's
     # loop with and without the flag (only the three N = 4096 injected layers are long enough to take it)

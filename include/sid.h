@@ -172,7 +172,10 @@ int sid_injected_attn_fwd_packed(const void* x_q, const void* q_cnt,
  *                               Only the two style blocks are computed.  Results equal those of the
  *                               other entry points the way two decompositions of one call are equal
  *                               (each part rounds its probabilities against its own reference).
- *                               SID_FLAG_BLOCK_SKIP is ignored.  Workspace:
+ *                               SID_FLAG_BLOCK_SKIP applies under the same conditions as in the other
+ *                               entry points: the bounds take every row's smallest content logit from
+ *                               the partial (exact, no sampling), and a workgroup whose far style block
+ *                               is dead runs the near one alone.  Workspace:
  *                               sid_injected_attn_cached_workspace_bytes.
  */
 size_t sid_content_partial_bytes(int B, int H, int N, int d, int compute);
@@ -220,12 +223,14 @@ int sid_injected_attn_fwd_static(const void* x_q, const void* q_cnt,
                                  int dtype, int compute, int flags, void* stream);
 
 /*
- * Where the four block-skipping counters of the last sid_injected_attn_fwd[_packed] call with these
+ * Where the four block-skipping counters of the last sid_injected_attn_fwd[_packed|_cached] call with these
  * arguments sit in its workspace (byte offset of 4 x uint32: key-block segments dropped, content segments
  * reduced to their logits, such segments redone in full, segments seen), or -1 when the flag has no effect
  * for the shape and mode.  A call also ignores the flag, and then leaves the counters unwritten, when its
  * T or scale is not positive or T * scale * log2(e) < 2^-30: read the counters only after calls outside
- * that range.  No counterpart in the reference: measurement and tests.
+ * that range.  `packed`: 0 = sid_injected_attn_fwd (the workspace holds the K/V images), 1 =
+ * sid_injected_attn_fwd_packed, 2 = sid_injected_attn_fwd_cached.  No counterpart in the reference:
+ * measurement and tests.
  */
 long long sid_injected_attn_skip_counts_offset(int B, int H, int N, int d, int compute, int flags, int packed);
 

@@ -155,7 +155,8 @@ class CrossAttention(nn.Module):
                     # (FeatureStore.pack(cache_content=True)): only the two style blocks are left
                     out = ops.injected_attention_cached(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, partial, m,
                                                         gamma, T, self.scale, self.heads, q_self_coef=0.5,
-                                                        flags=self.kernel_flags & ~ops.FLAG_BLOCK_SKIP)
+                                                        flags=self.kernel_flags)
+                    self._review_block_skip(xq, k_injected.compute, "cached", T)
                     return self.to_out(out)
                 out = ops.injected_attention_packed(xq.contiguous(), q_cnt, k_injected, sty2_k_injected, cnt_k_injected, m,
                                                     gamma, T, self.scale, self.heads, q_self_coef=0.5,

@@ -459,6 +459,8 @@ int make_geometry(int B, int H, int Nq, int Nk, int d, int nblk, bool x3, bool t
     for (int k = 0; k <= kMaxRuns; ++k) g->bound2[k] = 0;
     for (int b = 0; b < 2; ++b) { g->first_run2[b] = 0; g->nseg2[b] = 0; }
     if (skip && nblk == kBlocks && W <= 2 * stages) cut(2, g->bound2, g->first_run2, g->nseg2);
+    // (content block cached: the style block that is left takes all W runs, so a block has W partial slots)
+    if (skip && nblk == 2 && W <= stages) cut(1, g->bound2, g->first_run2, g->nseg2);
     g->NKT = stages * g->KVS;                             // whole stages; surplus tiles are zero
     g->lds = (size_t)ring_stages(g->DKS, g->DVB, x3) * g->KVS * tile_bytes(g->DKS, g->DVB, x3);
     g->q_units = (size_t)BH * g->NQT * g->DKS * 64;
@@ -502,7 +504,7 @@ void carve(const Geometry& g, int nblk, int nq, bool x3, long long rows, int d, 
         w->stats = (float*)take((size_t)np * rows * 16);
     }
     w->rowmap = w->rowmap_groups = nullptr; w->skip_count = nullptr; w->skip_count_off = 0;
-    if (nblk == kBlocks) {
+    if (nblk >= 2) {
         const size_t BH = g.q_units / ((size_t)g.DKS * 64) / g.NQT;
         w->skip_count_off = off;
         w->skip_count = (unsigned*)take(256);
@@ -690,6 +692,30 @@ float dead_gap(int N) {
     return kDeadGapBase + std::ceil(std::log2((float)N));
 }
 
+// Block skipping, shared by the three-block call and the call with a cached content block: the token
+// regrouping rides in the pack launch (one extra workgroup per image), the flash kernel gets the map, the
+// sampling plan, the margin and the run table of the shortened sequence.
+void set_rowmap_job(PackParams& pp, const Geometry& g, const Workspace& w, const float* mask_signed, int B, int H, int N,
+                    float T, float scale) {
+    pp.rm_mask = mask_signed; pp.rm_out = w.rowmap; pp.rm_groups = w.rowmap_groups; pp.rm_counters = w.skip_count;
+    pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32;
+    pp.rm_ts = std::max(T * scale, 0.5f);    // |m| <= 1/2: the blurred boundary of a +-1 mask (its values are +-1, +-1/2, 0)
+    // one round of workgroups (one per CU at 8 waves, two at 4): the slowest workgroup sets the time
+    const long long wgs = (long long)B * H * (g.nQG + kSkipPadGroups) * g.W;
+    pp.rm_own_middle = wgs <= 256LL * (g.NW == 8 ? 1 : 2);
+}
+void set_skip_params(FlashParams& fp, const Geometry& g, const Workspace& w, const float* mask_signed, int N, float T, float scale) {
+    fp.rowmap = w.rowmap; fp.rowmap_groups = w.rowmap_groups; fp.mask = mask_signed; fp.skip_count = w.skip_count;
+    fp.NP = (int)skip_positions(g);
+    const int full_tiles = N / 32;                      // key tiles without padding
+    fp.nsamp = std::min(kProbeTiles, full_tiles);
+    fp.samp_stride = full_tiles / fp.nsamp;
+    fp.ts = T * scale;
+    fp.dead_gap = dead_gap(N);
+    for (int k = 0; k <= g.W; ++k) fp.bound2[k] = g.bound2[k];
+    for (int b = 0; b < 2; ++b) { fp.first_run2[b] = g.first_run2[b]; fp.nseg2[b] = g.nseg2[b]; }
+}
+
 int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const void* v1,
                        const void* k2, const void* v2, const void* k_cnt, const void* v_cnt,
                        const float* mask_signed, void* out, int B, int H, int N, int d,
@@ -763,14 +789,7 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
         set_strides(pp.job[0], SID_LAYOUT_BNHD, H, N, d, true);
         rowjob(1, q_cnt, w.q[1][0], w.q[1][1], g.NQT, g.q_units);      // content query
         pp.job[1].post = c2c;
-        if (skip) {
-            pp.rm_mask = mask_signed; pp.rm_out = w.rowmap; pp.rm_groups = w.rowmap_groups; pp.rm_counters = w.skip_count;
-            pp.rm_N = N; pp.rm_NP = (int)skip_positions(g); pp.rm_GR = g.NW * g.QT * 32;
-            pp.rm_ts = std::max(T * scale, 0.5f);    // |m| <= 1/2: the blurred boundary of a +-1 mask (its values are +-1, +-1/2, 0)
-            // one round of workgroups (one per CU at 8 waves, two at 4): the slowest workgroup sets the time
-            const long long wgs = (long long)B * H * (g.nQG + kSkipPadGroups) * g.W;
-            pp.rm_own_middle = wgs <= 256LL * (g.NW == 8 ? 1 : 2);
-        }
+        if (skip) set_rowmap_job(pp, g, w, mask_signed, B, H, N, T, scale);
         const void* ks[kBlocks] = {k1, k2, k_cnt};
         const void* vs[kBlocks] = {v1, v2, v_cnt};
         for (int b = 0; b < kBlocks && !kv_images; ++b) {
@@ -795,15 +814,7 @@ int injected_attn_impl(const void* x_q, const void* q_cnt, const void* k1, const
     fp.c2[2] = c2c;
     if (skip) {
         if (g.bound2[g.W] != 2 * g.SPB) return sid::fail(SID_EINVAL, "internal: no two-block run table for W=%d SPB=%d", g.W, g.SPB);
-        fp.rowmap = w.rowmap; fp.rowmap_groups = w.rowmap_groups; fp.mask = mask_signed; fp.skip_count = w.skip_count;
-        fp.NP = (int)skip_positions(g);
-        const int full_tiles = N / 32;                      // key tiles without padding
-        fp.nsamp = std::min(kProbeTiles, full_tiles);
-        fp.samp_stride = full_tiles / fp.nsamp;
-        fp.ts = T * scale;
-        fp.dead_gap = dead_gap(N);
-        for (int k = 0; k <= g.W; ++k) fp.bound2[k] = g.bound2[k];
-        for (int b = 0; b < 2; ++b) { fp.first_run2[b] = g.first_run2[b]; fp.nseg2[b] = g.nseg2[b]; }
+        set_skip_params(fp, g, w, mask_signed, N, T, scale);
     }
     return run_flash_merge(fp, g, w, stg, mask_signed, out, scale, B, H, N, N, d, kBlocks, dtype, x3, stream, qk16);
 }
@@ -994,8 +1005,8 @@ extern "C" size_t sid_injected_attn_cached_workspace_bytes(int B, int H, int N, 
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return 0;
     const bool x3 = compute == SID_COMPUTE_F32X3;
     size_t bytes = 0;
-    for (int thr = 0; thr < 2; ++thr) {
-        if (make_geometry(B, H, N, N, d, 2, x3, thr != 0, &g) != SID_OK) return 0;
+    for (int v = 0; v < 4; ++v) {                // enough for any decomposition (SID_FLAG_THROUGHPUT, SID_FLAG_BLOCK_SKIP)
+        if (make_geometry(B, H, N, N, d, 2, x3, (v & 1) != 0, &g, (v & 2) != 0) != SID_OK) return 0;
         Workspace w;
         carve(g, 2, 1, x3, (long long)B * H * N, d, nullptr, &w, false);
         bytes = std::max(bytes, w.bytes);
@@ -1022,7 +1033,8 @@ extern "C" int sid_injected_attn_fwd_cached(const void* x_q, const void* q_cnt, 
                   "gamma, q_self_coef, T and scale must be finite");
     const bool x3 = compute == SID_COMPUTE_F32X3;
     Geometry g;
-    rc = make_geometry(B, H, N, N, d, 2, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g);
+    const bool skip = skip_applies(flags, compute, N, d, T, scale);
+    rc = make_geometry(B, H, N, N, d, 2, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g, skip);
     if (rc != SID_OK) return rc;
     const long long rows = (long long)B * H * N;
     Workspace w;
@@ -1056,11 +1068,17 @@ extern "C" int sid_injected_attn_fwd_cached(const void* x_q, const void* q_cnt, 
         j.src2 = x_q; j.c1 = gamma; j.c2 = q_self_coef; j.post = c2s;
         set_strides(j, SID_LAYOUT_BNHD, H, N, d, true);
         frags[0] = (long long)g.q_units;
-        rc = launch_pack(pp, frags, stream);
+        if (skip) set_rowmap_job(pp, g, w, mask_signed, B, H, N, T, scale);
+        rc = launch_pack(pp, frags, stream, skip ? B : 0);
         if (rc != SID_OK) return rc;
     }
     FlashParams fp = {};
     fp.shift_cols = has_shift_cols(d, g.DKS);
+    if (skip) {
+        if (g.bound2[g.W] != g.SPB) return sid::fail(SID_EINVAL, "internal: no one-block run table for W=%d SPB=%d", g.W, g.SPB);
+        set_skip_params(fp, g, w, mask_signed, N, T, scale);
+        fp.cstats = cached.stats;
+    }
     for (int b = 0; b < 2; ++b) {
         fp.q[b] = w.q[0][0]; fp.q_lo[b] = w.q[0][1];
         fp.k[b] = w.k[b][0]; fp.k_lo[b] = w.k[b][1];
@@ -1076,9 +1094,10 @@ extern "C" long long sid_injected_attn_skip_counts_offset(int B, int H, int N, i
     if (check_common(B, H, N, N, d, SID_DTYPE_F32, compute) != SID_OK) return -1;
     const bool x3 = compute == SID_COMPUTE_F32X3;
     if (!skip_applies(flags, compute, N, d, 1.f, 1.f)) return -1;
-    if (make_geometry(B, H, N, N, d, kBlocks, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g, true) != SID_OK) return -1;
+    const int nblk = packed == 2 ? 2 : kBlocks;          // 2: the workspace of sid_injected_attn_fwd_cached
+    if (make_geometry(B, H, N, N, d, nblk, x3, (flags & SID_FLAG_THROUGHPUT) != 0, &g, true) != SID_OK) return -1;
     Workspace w;
-    carve(g, kBlocks, 2, x3, (long long)B * H * N, d, nullptr, &w, packed == 0);
+    carve(g, nblk, nblk == 2 ? 1 : 2, x3, (long long)B * H * N, d, nullptr, &w, packed == 0);
     return (long long)w.skip_count_off;
 }
 
@@ -1092,7 +1111,7 @@ extern "C" int sid_attn_plan(int blocks, int B, int H, int Nq, int Nk, int d, in
     if (blocks == 1 && use_small_path(Nk, d)) return SID_OK;
     Geometry g;
     rc = make_geometry(B, H, Nq, Nk, d, blocks, compute == SID_COMPUTE_F32X3, (flags & SID_FLAG_THROUGHPUT) != 0, &g,
-                       blocks == kBlocks && skip_applies(flags, compute, Nq, d, 1.f, 1.f));
+                       blocks >= 2 && skip_applies(flags, compute, Nq, d, 1.f, 1.f));
     if (rc != SID_OK) return rc;
     plan[0] = g.W; plan[1] = g.G; plan[2] = g.SPB; plan[3] = g.KS; plan[4] = g.NW; plan[5] = g.QT; plan[6] = g.nQG;
     plan[7] = g.KVS * 32;

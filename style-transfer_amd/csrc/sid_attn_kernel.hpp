@@ -84,6 +84,10 @@ struct FlashParams {
     float ts, dead_gap;
     unsigned short bound2[kMaxRuns + 1];
     unsigned char first_run2[2], nseg2[2];
+    // block skipping with the content block cached (nblk == 2): the statistics of the cached partial,
+    // [BH][Nq][4]; entry 3 of a row is its smallest raw content logit, which the bounds then take exactly
+    // instead of from samples.  A group with a dead style block runs the other one alone: bound2 cuts ONE block.
+    const float* cstats;
     int nblk;                    // 3: injected [char | back | content], 2: the style blocks alone (the content
                                  // block comes from a cached partial), 1: single block
     int content_only;            // nblk == 1 and the block is a content block whose partial is kept: its smallest
@@ -135,6 +139,8 @@ constexpr size_t tile_bytes(int DKS, int DVB, bool x3) { return (size_t)(DKS + 2
 // tiles per LDS stage: two, unless two double-buffered stages exceed what lets two workgroups share a CU
 constexpr int stage_tiles(int DKS, int DVB, bool x3) { return 2 * 2 * tile_bytes(DKS, DVB, x3) <= 80 * 1024 ? 2 : 1; }
 // query tiles per wave: two where the accumulators of both fit the 256-register budget
+// (SID_WIDE_QT: measurement builds only -- 4 with SID_TUNE_NW=4 runs one wave per SIMD over four query
+// tiles, 512 registers per lane; measured equal to the shipped two waves x two tiles at head_dim 40)
 #ifndef SID_WIDE_QT
 #define SID_WIDE_QT 2
 #endif
@@ -652,7 +658,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
         const int b_ = bh / P.H;
         if (qg >= P.rowmap_groups[b_]) return;            // the whole workgroup: a padding group of the launch
 #pragma unroll
-        for (int t = 0; t < QT; ++t) tok[t] = P.rowmap[(size_t)b_ * P.NP + (qt0 + t) * 32 + (lane & 31)];
+        for (int t = 0; t < QT; ++t) {
+            // (anything that is not a token of the image counts as padding: a map that a measurement call with
+            // a stage flag finds overwritten by another call must not turn into addresses)
+            const int tk = P.rowmap[(size_t)b_ * P.NP + (qt0 + t) * 32 + (lane & 31)];
+            tok[t] = (unsigned)tk < (unsigned)P.Nq ? tk : -1;
+        }
     }
     // a wave of padding alone (the tail of a mask side): no arithmetic, only its share of copies and barriers
     bool wave_live = true;
@@ -699,19 +710,28 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
     unsigned gflags = 0;
     float row_lb[SKIP ? QT : 1];
     if constexpr (SKIP) {
+        // (content block cached: no content images in the call; min_j xc comes from the partial's statistics
+        // and the content block is never a candidate)
+        const bool with_content = P.nblk == kBlocks;
         Frags<DKS, false> qb[QT], qc[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             qb[t].load(q_frag_ptr(P.q[0], t), 0);
-            qc[t].load(q_frag_ptr(P.q[kBlocks - 1], t), 0);
+            qc[t] = qb[t];
+            if (with_content) qc[t].load(q_frag_ptr(P.q[kBlocks - 1], t), 0);
         }
         float xs[kBlocks][QT], cmn[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) cmn[t] = SID_INF;
+        for (int t = 0; t < QT; ++t) {
+            cmn[t] = SID_INF;
+            if (!with_content && tok[t] >= 0)
+                cmn[t] = P.cstats[((size_t)bh * P.Nq + tok[t]) * 4 + 3] * P.c2[kBlocks - 1];
+        }
 #pragma unroll
         for (int b = 0; b < kBlocks; ++b) {
 #pragma unroll
             for (int t = 0; t < QT; ++t) xs[b][t] = -SID_INF;
+            if (b == kBlocks - 1 && !with_content) continue;
             // a fixed trip count with a clamped index (a repeated tile changes no extreme): the loads do not
             // depend on each other, so as many are in flight as registers allow
 #pragma unroll
@@ -746,7 +766,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
                     d1 = far_dead && m < 0.f;
                     d2 = far_dead && m > 0.f;
                     // a guess with half the sampled range of headroom
-                    dc = lbv - (cmax + 0.5f * (cmax - cmin)) >= P.dead_gap;
+                    dc = with_content && lbv - (cmax + 0.5f * (cmax - cmin)) >= P.dead_gap;
                     row_lb[t] = lbv;
                 }
                 bad |= (d1 ? 0u : 1u) | (d2 ? 0u : 2u) | (dc ? 0u : 4u);

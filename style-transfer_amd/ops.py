@@ -132,7 +132,8 @@ def skip_counts(x_q, heads, compute="f16", flags=FLAG_BLOCK_SKIP, packed=False, 
     """The block-skipping counters of the last injected-attention call made on the current stream with this
     shape, mode, flags and entry point: (query groups with a dead style block, content segments reduced to
     their logits, of those redone in full, query groups), or None where the flag has no effect (then the
-    call ran as if it were not set).  Pass the call's T and scale: the library ignores the flag for
+    call ran as if it were not set).  `packed`: False = injected_attention, True = injected_attention_packed,
+    "cached" = injected_attention_cached.  Pass the call's T and scale: the library ignores the flag for
     non-positive or vanishing logit scales, and the counters of such a call are not written.  Synchronises."""
     L = _lib.load()
     B, N, C = x_q.shape
@@ -140,7 +141,8 @@ def skip_counts(x_q, heads, compute="f16", flags=FLAG_BLOCK_SKIP, packed=False, 
         log2e = 1.4426950408889634
         if not (T > 0 and scale > 0 and T * scale * log2e >= 2.0 ** -30 and scale * log2e >= 2.0 ** -30):
             return None
-    off = L.sid_injected_attn_skip_counts_offset(B, heads, N, C // heads, _compute_code(compute), int(flags), int(packed))
+    off = L.sid_injected_attn_skip_counts_offset(B, heads, N, C // heads, _compute_code(compute), int(flags),
+                                                 2 if packed == "cached" else int(bool(packed)))
     if off < 0:
         return None
     ws = _workspaces.get((x_q.device.index, _stream(x_q.device)))

@@ -357,3 +357,122 @@ def test_auto_policy_keeps_the_flag_only_where_blocks_die(sigma, kept, tmp_path)
     ref = run(t, d, MODE, 0)
     for out in (first, second):
         assert (out - ref).abs().max().item() <= SAME_BAND * ref.abs().max().item()
+
+
+# ---- the call whose content block comes from a cached partial (sid_injected_attn_fwd_cached)
+
+def cached_run(t, d, compute, flags, T=1.5):
+    kv = [ops.pack_kv(t[k], t[v], H, compute) for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    partial = ops.content_partial(t["q_cnt"], kv[2], d ** -0.5, H)
+    return ops.injected_attention_cached(t["xq"], t["q_cnt"], kv[0], kv[1], partial, t["mask"], 0.5, T, d ** -0.5, H,
+                                         flags=flags)
+
+
+@pytest.mark.parametrize("N,d,sigma,mask,B", [
+    (4096, 40, 3.0, "halves", 1), (4096, 40, 2.0, "disc", 2), (4096, 40, 3.0, "random", 1), (4096, 40, 3.0, "soft", 1),
+    (4096, 40, 1.0, "disc", 1), (4000, 40, 3.0, "halves", 2), (2500, 40, 3.0, "disc", 1), (2048, 80, 3.0, "halves", 1),
+    (2048, 160, 3.0, "disc", 1), (2080, 64, 3.0, "disc", 1),
+])
+def test_cached_content_block_takes_the_flag(N, d, sigma, mask, B, monkeypatch):
+    """Two style blocks in the call: a query group whose far style block is dead runs the near one alone, and the
+    bounds take the smallest content logit of every row from the partial."""
+    t = inputs(8000 + N + int(sigma) + d, B, N, d, sigma, mask)
+    plain = cached_run(t, d, MODE, 0)
+    skipped = cached_run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE, packed="cached")
+    monkeypatch.setenv("SID_TUNE_DEAD_GAP", "1e30")
+    kept = cached_run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    kept_counts = ops.skip_counts(t["xq"], H, MODE, packed="cached")
+    monkeypatch.delenv("SID_TUNE_DEAD_GAP")
+    scale = plain.abs().max().item()
+    print("cached N=%d d=%d sigma=%.0f %s B=%d: counts %s, max diff %.2e of %.2e" % (
+        N, d, sigma, mask, B, (dead, lo, redone, groups), (plain - skipped).abs().max().item(), scale))
+    assert torch.isfinite(skipped).all()
+    assert lo == 0 and redone == 0 and groups > 0           # no content segments in this call
+    assert kept_counts[0] == 0 and kept_counts[3] == groups
+    assert (kept - skipped).abs().max().item() <= SAME_BAND * scale
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * scale
+    if mask in ("halves", "disc", "random") and sigma >= 2.0:
+        assert dead == groups
+    if mask == "soft":
+        assert 0 < dead < groups
+    if sigma < 2.0:
+        assert dead < groups
+    # the bounds are at least as sharp as the three-block call's (the exact content minimum instead of a sample)
+    run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    assert dead >= ops.skip_counts(t["xq"], H, MODE)[0]
+    rows = (synth.hash_u64(8001, 10) % np.uint64(N)).astype(np.int64)
+    for b in range(B):
+        assert rel_err(skipped[b].cpu().numpy()[rows], oracle_rows(t, b, rows, d)) < BAR[MODE]
+
+
+def test_cached_call_with_a_towering_key_in_the_dead_looking_block():
+    """The adversarial style key of test_sampled_bounds_never_drop_a_block_that_matters, content block cached."""
+    N, d = 4096, 40
+    t = inputs(8100, 1, N, d, 3.0, "halves")
+    t["k2"][:, 2001] *= 6.0
+    t["k1"][:, 77] *= 5.0
+    plain = cached_run(t, d, MODE, 0)
+    skipped = cached_run(t, d, MODE, ops.FLAG_BLOCK_SKIP)
+    assert (plain - skipped).abs().max().item() <= SAME_BAND * plain.abs().max().item()
+    rows = np.array([0, 100, 101, 255, 2047, 2048, 4095])
+    assert rel_err(skipped[0].cpu().numpy()[rows], oracle_rows(t, 0, rows, d)) < BAR[MODE]
+
+
+def test_cached_call_with_throughput_flag_bf16_storage_and_graph_replay():
+    N, d = 4096, 40
+    t = inputs(8200, 2, N, d, 3.0, "disc")
+    t["mask"][1] = -t["mask"][1]
+    tb = {k: (v.bfloat16() if k != "mask" else v) for k, v in t.items()}
+    both = ops.FLAG_BLOCK_SKIP | ops.FLAG_THROUGHPUT
+    plain = cached_run(tb, d, MODE, ops.FLAG_THROUGHPUT)
+    kv = [ops.pack_kv(tb[k], tb[v], H, MODE) for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    partial = ops.content_partial(tb["q_cnt"], kv[2], d ** -0.5, H)
+    out = torch.empty_like(tb["xq"])
+    call = lambda: ops.injected_attention_cached(tb["xq"], tb["q_cnt"], kv[0], kv[1], partial, tb["mask"], 0.5, 1.5, d ** -0.5, H,
+                                                 out=out, flags=both)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        call()
+        eager = out.clone()
+        dead, lo, redone, groups = ops.skip_counts(tb["xq"], H, MODE, flags=both, packed="cached")
+        assert dead == groups and groups > 0
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            call()
+        out.zero_()
+        graph.replay()
+    st.synchronize()
+    assert torch.equal(out, eager)
+    assert (plain.float() - out.float()).abs().max().item() <= 2 * SAME_BAND * plain.float().abs().max().item()
+    rows = (synth.hash_u64(8201, 8) % np.uint64(N)).astype(np.int64)
+    tf = {k: (v.float() if k != "mask" else v) for k, v in tb.items()}
+    for b in (0, 1):
+        assert rel_err(out[b].float().cpu().numpy()[rows], oracle_rows(tf, b, rows, d)) < BAR[MODE]
+
+
+def test_module_passes_the_flag_to_the_cached_call(tmp_path):
+    """CrossAttention with a store-cached content block and skip_policy "auto"."""
+    from style_transfer_amd.attention import CrossAttention
+    N, d = 4096, 40
+    t = inputs(8300, 1, N, d, 3.0, "disc")
+    np.save(str(tmp_path / "img_mask.npy"), (t["mask"][0].reshape(64, 64) > 0).float().cpu().numpy())
+    attn = CrossAttention(query_dim=H * d, heads=H, dim_head=d).to("cuda:0")
+    with torch.no_grad():
+        attn.to_q.weight.copy_(torch.eye(H * d)); attn.to_out[0].weight.copy_(torch.eye(H * d)); attn.to_out[0].bias.zero_()
+    attn.cnt_name = str(tmp_path / "img.jpg")
+    attn.kernel_flags |= ops.FLAG_BLOCK_SKIP
+    attn.skip_policy = "auto"
+    kv = [ops.pack_kv(t[k], t[v], H, MODE) for k, v in (("k1", "v1"), ("k2", "v2"), ("k_cnt", "v_cnt"))]
+    kv[2].partial = ops.content_partial(t["q_cnt"], kv[2], attn.scale, H)
+    kw = dict(q_injected=t["q_cnt"], k_injected=kv[0], v_injected=kv[0], sty2_k_injected=kv[1], sty2_v_injected=kv[1],
+              cnt_k_injected=kv[2], cnt_v_injected=kv[2], injection_config={"T": 1.5, "gamma": 0.5})
+    with torch.no_grad():
+        first = attn(t["xq"], **kw)
+        assert attn.skip_policy == "fixed" and attn.kernel_flags & ops.FLAG_BLOCK_SKIP
+        dead, lo, redone, groups = ops.skip_counts(t["xq"], H, MODE, packed="cached")
+        assert dead == groups and groups > 0
+        second = attn(t["xq"], **kw)
+    ref = run(t, d, MODE, 0)
+    for out in (first, second):
+        assert (out - ref).abs().max().item() <= SAME_BAND * ref.abs().max().item()
