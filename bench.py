@@ -333,6 +333,7 @@ def block_skip_record(dev, compute):
                                                              HEADS, out=out, flags=fl)
             tc_off = events_per_call(lambda: ccall(0), reps)
             tc_on = events_per_call(lambda: ccall(ops.FLAG_BLOCK_SKIP), reps)
+            ccall(ops.FLAG_BLOCK_SKIP)
             ccounts = ops.skip_counts(xq, HEADS, mode, packed="cached")
             rec["cases"].append({"B": B, "feature_sigma": sigma, "call_ms_flag_off": t_off * 1e3, "call_ms_flag_on": t_on * 1e3,
                                  "time_ratio": t_on / t_off,
@@ -354,16 +355,22 @@ def block_skip_record(dev, compute):
             w = make_image_workload(dev, gen, torch.float32, "packed", mode, sigma=sigma)
             st = lane_stream(dev, li)
             graphs = {}
-            for name, fl in (("off", ops.FLAG_THROUGHPUT), ("on", ops.FLAG_THROUGHPUT | ops.FLAG_BLOCK_SKIP)):
+            jobs = [(q_cnt, kv[2], layer["d"] ** -0.5) for layer in w["inj"] for q_cnt, kv in layer["feats"]]
+            for (_, kvc, _), partial in zip(jobs, ops.content_partials(jobs, HEADS)):
+                kvc.partial = partial
+            torch.cuda.synchronize()
+            both = ops.FLAG_THROUGHPUT | ops.FLAG_BLOCK_SKIP
+            for name, fl, cached in (("off", ops.FLAG_THROUGHPUT, False), ("on", both, False),
+                                     ("cached_off", ops.FLAG_THROUGHPUT, True), ("cached_on", both, True)):
                 with torch.cuda.stream(st):
-                    run_image(w, mode, fl)
+                    run_image(w, mode, fl, cached)
                 torch.cuda.synchronize()
                 graphs[name] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graphs[name], stream=st, capture_error_mode="thread_local"):
-                    run_image(w, mode, fl)
+                    run_image(w, mode, fl, cached)
             lanes.append((st, graphs, w))
         rates = {}
-        for name in ("off", "on"):
+        for name in ("off", "on", "cached_off", "cached_on"):
             for timed in (False, True):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -376,7 +383,10 @@ def block_skip_record(dev, compute):
                     rates[name] = images / (time.perf_counter() - t0)
         rec["image"].append({"what": "hot path of one image as in `value` (same lanes), attention tensors x%g (feature-sized logits)" % sigma,
                              "feature_sigma": sigma, "imgs_per_s_flag_off": rates["off"], "imgs_per_s_flag_on": rates["on"],
-                             "ratio": rates["on"] / rates["off"]})
+                             "ratio": rates["on"] / rates["off"],
+                             "content_cached": {"imgs_per_s_flag_off": rates["cached_off"], "imgs_per_s_flag_on": rates["cached_on"],
+                                                "ratio": rates["cached_on"] / rates["cached_off"],
+                                                "ratio_to_three_blocks_flag_off": rates["cached_on"] / rates["off"]}})
         del lanes
         torch.cuda.empty_cache()
     return rec

@@ -711,41 +711,47 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
     float row_lb[SKIP ? QT : 1];
     if constexpr (SKIP) {
         // (content block cached: no content images in the call; min_j xc comes from the partial's statistics
-        // and the content block is never a candidate)
+        // and the content block is never a candidate.  Two instantiations of one probe behind a uniform branch,
+        // so that each is the straight-line code it would be alone)
         const bool with_content = P.nblk == kBlocks;
-        Frags<DKS, false> qb[QT], qc[QT];
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            qb[t].load(q_frag_ptr(P.q[0], t), 0);
-            qc[t] = qb[t];
-            if (with_content) qc[t].load(q_frag_ptr(P.q[kBlocks - 1], t), 0);
-        }
         float xs[kBlocks][QT], cmn[QT];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            cmn[t] = SID_INF;
-            if (!with_content && tok[t] >= 0)
-                cmn[t] = P.cstats[((size_t)bh * P.Nq + tok[t]) * 4 + 3] * P.c2[kBlocks - 1];
-        }
+        for (int t = 0; t < QT; ++t) cmn[t] = SID_INF;
 #pragma unroll
-        for (int b = 0; b < kBlocks; ++b) {
+        for (int b = 0; b < kBlocks; ++b)
 #pragma unroll
             for (int t = 0; t < QT; ++t) xs[b][t] = -SID_INF;
-            if (b == kBlocks - 1 && !with_content) continue;
-            // a fixed trip count with a clamped index (a repeated tile changes no extreme): the loads do not
-            // depend on each other, so as many are in flight as registers allow
+        auto probe = [&](auto wc) {
+            constexpr bool WC = decltype(wc)::value;
+            Frags<DKS, false> qb[QT], qc[WC ? QT : 1];
 #pragma unroll
-            for (int j = 0; j < kProbeTiles; ++j) {
-                Frags<DKS, false> kf;
-                kf.load(P.k[b] + ((size_t)(bh * P.NKT + min(j, P.nsamp - 1) * P.samp_stride) * DKS) * 64 + lane, 0);
+            for (int t = 0; t < QT; ++t) {
+                qb[t].load(q_frag_ptr(P.q[0], t), 0);
+                if constexpr (WC) qc[t].load(q_frag_ptr(P.q[kBlocks - 1], t), 0);
+            }
+            if constexpr (!WC) {
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    const f32x16 S = qk_tile<DKS, false, QK16>(kf, b == kBlocks - 1 ? qc[t] : qb[t]);
-                    xs[b][t] = fmaxf(xs[b][t], max16(S));
-                    if (b == kBlocks - 1) cmn[t] = fminf(cmn[t], min16(S));
+                for (int t = 0; t < QT; ++t)
+                    if (tok[t] >= 0) cmn[t] = P.cstats[((size_t)bh * P.Nq + tok[t]) * 4 + 3] * P.c2[kBlocks - 1];
+            }
+#pragma unroll
+            for (int b = 0; b < (WC ? kBlocks : 2); ++b) {
+                // a fixed trip count with a clamped index (a repeated tile changes no extreme): the loads do not
+                // depend on each other, so as many are in flight as registers allow
+#pragma unroll
+                for (int j = 0; j < kProbeTiles; ++j) {
+                    Frags<DKS, false> kf;
+                    kf.load(P.k[b] + ((size_t)(bh * P.NKT + min(j, P.nsamp - 1) * P.samp_stride) * DKS) * 64 + lane, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const f32x16 S = qk_tile<DKS, false, QK16>(kf, (WC && b == kBlocks - 1) ? qc[WC ? t : 0] : qb[t]);
+                        xs[b][t] = fmaxf(xs[b][t], max16(S));
+                        if (WC && b == kBlocks - 1) cmn[t] = fminf(cmn[t], min16(S));
+                    }
                 }
             }
-        }
+        };
+        if (with_content) probe(std::true_type{}); else probe(std::false_type{});
         unsigned bad = 0;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
