@@ -78,7 +78,9 @@ extern "C" {
 #define SID_FLAG_THROUGHPUT 2
 /* Stage selection for measurement: an attention call is pack -> flash -> merge.  With none of
  * these bits set all three run.  A call that leaves out an earlier stage reuses what a previous
- * call with the same shape arguments left in the same workspace. */
+ * call of the SAME entry point with the same shape arguments, mode and flags left in the same workspace
+ * (every entry point lays the workspace out its own way); after anything else the results are garbage
+ * (never addresses: what a kernel reads from the workspace is range-checked before it is used as an index). */
 #define SID_FLAG_STAGE_PACK 0x10
 #define SID_FLAG_STAGE_FLASH 0x20
 #define SID_FLAG_STAGE_MERGE 0x40
