@@ -766,6 +766,7 @@ def sweep_record(dev, compute, n_cnt=2, n_char=2, n_back=2, reference_lines=3):
         rec["prefetch_lru_pickles"] = run(["--sidecar", "write"], every)                     # also writes the side-cars
         rec["prefetch_lru_sidecars"] = run(["--sidecar", "use"], every)
         rec["prefetch_lru_sidecars_4_lanes"] = run(["--sidecar", "use", "--lanes", "4"], every)
+        rec["prefetch_lru_sidecars_4_lanes_network_autocast"] = run(["--sidecar", "use", "--lanes", "4", "--network_autocast"], every)
         rec["sidecar_GB"] = sum(os.path.getsize(os.path.join(pre, n)) for n in os.listdir(pre) if n.endswith(".sidpack")) / 1e9
         # compute only: the same lines with every list already resident (a second pass over a warm loader is not what
         # run_lines does, so: the e2e record's rate for one image at a time)

@@ -46,7 +46,9 @@ def build_parser():
     p.add_argument('--model_config', type=str, default='models/ldm/stable-diffusion-v1/v1-inference.yaml')
     p.add_argument('--precomputed', type=str, default='./precomputed_feats_k')
     p.add_argument('--ckpt', type=str, default='models/ldm/stable-diffusion-v1/model.ckpt')
-    p.add_argument('--precision', type=str, default='autocast')
+    p.add_argument('--precision', type=str, default='autocast',
+                   help="accepted as in the reference, whose two-style loop parses it and never reads it (run_ori.py:111): the "
+                        "network runs in the precision of its weights; see --network_autocast")
     p.add_argument('--output_path', type=str, default='output_dk')
     p.add_argument("--without_init_adain", action='store_true')
     p.add_argument("--without_attn_injection", action='store_true')
@@ -74,6 +76,9 @@ def build_parser():
     p.add_argument('--lanes', type=int, default=1,
                    help="images in flight on one GPU: each lane replays its own HIP graph of the UNet evaluation on its own stream "
                         "(implies --graph_unet; lines whose content has a residual file are stylised one at a time)")
+    p.add_argument('--network_autocast', action='store_true',
+                   help="run the host network under bf16 autocast (convolutions and linears in bf16, as hf_run.py:285,418 does "
+                        "with fp16 on its hardware); the attention kernels then read bf16 activations: 1.6x end to end")
     p.add_argument('--progress', action='store_true', help="one line on stderr per finished batch of lines")
     p.add_argument('--no_prefetch', action='store_true', help="read the feature files of a line only when its turn comes (the reference's order)")
     p.add_argument('--sidecar', default='use', choices=['off', 'use', 'write'],
@@ -292,7 +297,10 @@ def run_lines(opt, model, sampler, triples, mine, uc, device):
 
     for j in (batches[0] if batches else []):
         loader.request(keys[j])
-    with torch.no_grad():
+    import contextlib
+    scope = (torch.autocast("cuda", dtype=torch.bfloat16) if getattr(opt, "network_autocast", False)
+             else contextlib.nullcontext())
+    with torch.no_grad(), scope:
         for bi, batch in enumerate(batches):
             stores = [loader.get(keys[j]) for j in batch]
             for j in (batches[bi + 1] if bi + 1 < len(batches) else []):

@@ -262,6 +262,34 @@ def test_lanes_give_the_latents_of_one_at_a_time(tmp_path):
     assert not torch.equal(got[0], got[2]) and not torch.equal(got[0], got[1])
 
 
+def test_network_autocast_flag(tmp_path):
+    """`--network_autocast`: the host network's convolutions and linears in bf16, the attention kernels on bf16
+    activations; two-style lines (one at a time and in lanes) and a single-style line stay within 40 dB of the
+    full-precision run (the reference-loop pin of this mode is in test_gpu_unet)."""
+    from style_transfer_amd import run as cli
+    root, pre = make_root(tmp_path, ["c1.jpg a.png b.png", "c2.jpg a.png b.png"], masks=("c1", "c2"))
+    load = lambda name: torch.load(str(tmp_path / name / "latents_all.pt"), weights_only=True).numpy()
+    psnr = lambda ref, got: 10 * np.log10(float(ref.max() - ref.min()) ** 2 / max(float(((ref - got) ** 2).mean()), 1e-300))
+    cli.main(cli_args(tmp_path, root, pre, "full"))
+    cli.main(cli_args(tmp_path, root, pre, "auto") + ["--network_autocast"])
+    cli.main(cli_args(tmp_path, root, pre, "auto_lanes") + ["--network_autocast", "--lanes", "2"])
+    want = load("full")
+    for name in ("auto", "auto_lanes"):
+        got = load(name)
+        assert got.shape == want.shape and np.isfinite(got).all()
+        db = [psnr(want[i], got[i]) for i in range(len(want))]
+        print("%s: PSNR to the full-precision run %s dB" % (name, ["%.1f" % x for x in db]))
+        assert min(db) >= 40.0
+        assert not np.array_equal(got, want)                           # the flag did something
+    # a single-style line (no mask file: the StyleID branch) under autocast
+    sub = tmp_path / "s"
+    root2, pre2 = make_root(sub, ["c1.jpg a.png"])
+    cli.main(cli_args(sub, root2, pre2, "full"))
+    cli.main(cli_args(sub, root2, pre2, "auto") + ["--network_autocast"])
+    one = lambda name: torch.load(str(sub / name / "latents_all.pt"), weights_only=True).numpy()
+    assert psnr(one("full")[0], one("auto")[0]) >= 40.0
+
+
 def test_sweep_of_16_lines_over_two_ranks_with_lanes(tmp_path):
     """The data_vis sweep in small: 16 lines = 4 contents x 2 character x 2 background styles, started the way
     the driver starts ranks (here both ranks on the one GPU of the box, the gather through the host), two
