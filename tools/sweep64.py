@@ -8,6 +8,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # what run.py --lanes asks for (before the runtime starts)
 import torch
 import bench
 from style_transfer_amd import lib
