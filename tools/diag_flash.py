@@ -13,7 +13,8 @@ os.environ.setdefault("SID_LIB_OVERRIDE", os.path.join(os.path.dirname(os.path.d
 from style_transfer_amd import ops
 H = 8
 g = torch.Generator(device=dev); g.manual_seed(0)
-rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+scale = float(os.environ.get("SID_DIAG_SCALE", "1"))      # 0: all-zero operands (same instructions, no switching in the multipliers)
+rn = lambda *s: torch.randn(*s, device=dev, generator=g) * scale
 xq = rn(B, N, H * d); f = [rn(B * H, N, d) for _ in range(7)]; m = torch.sign(rn(B, N)).contiguous()
 plain = len(sys.argv) > 4 and sys.argv[4] == "plain"
 pq, pk, pv = (rn(B, N, H * d) for _ in range(3))
