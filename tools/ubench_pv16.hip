@@ -22,18 +22,28 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define CVT(d, x, y) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
 #define SWAP(a, b) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 
+// Operand bits: near-constant values (little switching in the multipliers: the clock stays high and the figures
+// compare CYCLES) or, with rnd, a pair of bf16 with random sign and mantissa in [0.5, 2) per lane and register (the
+// power-limited regime the real kernel runs in: the figures then compare what the clock management leaves).
+__device__ __forceinline__ unsigned operand_bits(int rnd, unsigned plain, unsigned salt) {
+    if (!rnd) return plain;
+    unsigned h = (threadIdx.x * 2654435761u) ^ (salt * 40503u + 0x9e3779b9u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    return (h & 0x80ff80ffu) | 0x3f003f00u;
+}
+
 // MODE 0: the kernel's slot (A).  MODE 1: P.V as six 16x16x32 MFMAs plus the swaps (B).  MODE 3: mixed (C).
 // MODE 2: B without the swaps (the matrix side alone).  EXTRA (bits): 1 LDS reads, 2 barrier, 4 scalar work as in the kernel.
 template <int MODE, int EXTRA>
-__global__ void __launch_bounds__(512) bench(float* out, int iters) {
+__global__ void __launch_bounds__(512) bench(float* out, int iters, int rnd) {
     f32x16 O0, O1, SA, SB;
     f32x4 o16[6];
     for (int i = 0; i < 16; ++i) { O0[i] = O1[i] = SA[i] = SB[i] = 0.f; }
     for (int j = 0; j < 6; ++j) for (int i = 0; i < 4; ++i) o16[j][i] = 0.f;
     u32x4 kf[3], qf[3], vf[4], PA[2], PB[2];
     for (int i = 0; i < 4; ++i) {
-        for (int j = 0; j < 3; ++j) { kf[j][i] = 0x3c003c00u + threadIdx.x + j; qf[j][i] = 0x3c003c00u + i + j; }
-        for (int j = 0; j < 4; ++j) vf[j][i] = 0x3c003c00u + i * j;
+        for (int j = 0; j < 3; ++j) { kf[j][i] = operand_bits(rnd, 0x3c003c00u + threadIdx.x + j, 4 * j + i); qf[j][i] = operand_bits(rnd, 0x3c003c00u + i + j, 64 + 4 * j + i); }
+        for (int j = 0; j < 4; ++j) vf[j][i] = operand_bits(rnd, 0x3c003c00u + i * j, 128 + 4 * j + i);
         for (int j = 0; j < 2; ++j) { PA[j][i] = PB[j][i] = 0x3c003c00u; }
     }
     float e[16], m = 0.f;
@@ -135,14 +145,14 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
 // work (16 exp, 8 max3, 8 cvt_pk per lane and unit), same fragment reads (4 K + 3 V per two units).
 #define MFMA16_ZERO(acc, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
 template <int EXTRA>
-__global__ void __launch_bounds__(512) bench16(float* out, int iters) {
+__global__ void __launch_bounds__(512) bench16(float* out, int iters, int rnd) {
     f32x4 SA[4], SB[4], o16[6];
     for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) SA[j][i] = SB[j][i] = 0.f;
     for (int j = 0; j < 6; ++j) for (int i = 0; i < 4; ++i) o16[j][i] = 0.f;
     u32x4 kf[4], qf[4], vf[3], PA[2], PB[2];
     for (int i = 0; i < 4; ++i) {
-        for (int j = 0; j < 4; ++j) { kf[j][i] = 0x3c003c00u + threadIdx.x + j; qf[j][i] = 0x3c003c00u + i + j; }
-        for (int j = 0; j < 3; ++j) vf[j][i] = 0x3c003c00u + i * j;
+        for (int j = 0; j < 4; ++j) { kf[j][i] = operand_bits(rnd, 0x3c003c00u + threadIdx.x + j, 4 * j + i); qf[j][i] = operand_bits(rnd, 0x3c003c00u + i + j, 64 + 4 * j + i); }
+        for (int j = 0; j < 3; ++j) vf[j][i] = operand_bits(rnd, 0x3c003c00u + i * j, 128 + 4 * j + i);
         for (int j = 0; j < 2; ++j) { PA[j][i] = PB[j][i] = 0x3c003c00u; }
     }
     float e[16], m = 0.f;
@@ -207,6 +217,7 @@ __global__ void __launch_bounds__(512) bench16(float* out, int iters) {
 }
 
 static float* g_out;
+static int g_rnd = 0;
 
 template <int EXTRA>
 void run16(const char* name) {
@@ -214,9 +225,9 @@ void run16(const char* name) {
     for (int threads : {256, 512}) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        for (int i = 0; i < 2; ++i) bench16<EXTRA><<<grid, threads>>>(g_out, iters);
+        for (int i = 0; i < 2; ++i) bench16<EXTRA><<<grid, threads>>>(g_out, iters, g_rnd);
         (void)hipEventRecord(e0);
-        bench16<EXTRA><<<grid, threads>>>(g_out, iters);
+        bench16<EXTRA><<<grid, threads>>>(g_out, iters, g_rnd);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -231,9 +242,9 @@ void run(const char* name) {
     for (int threads : {256, 512}) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        for (int i = 0; i < 2; ++i) bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters);
+        for (int i = 0; i < 2; ++i) bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters, g_rnd);
         (void)hipEventRecord(e0);
-        bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters);
+        bench<MODE, EXTRA><<<grid, threads>>>(g_out, iters, g_rnd);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms;
@@ -242,9 +253,21 @@ void run(const char* name) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     (void)hipMalloc(&g_out, 256 * 512 * sizeof(float));
+    if (argc > 1) {      // any argument: the kernel's slot against the all-16x16x32 one, near-constant and random operands
+        for (int rep = 0; rep < 2; ++rep)
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                g_rnd = rnd;
+                printf("-- %s operands\n", rnd ? "random" : "near-constant");
+                run<0, 0>("A  P.V as 4 x 32x32x16 (the kernel's slot)");
+                run16<0>("D  all 16x16x32: 8 K.Q' + 6 P.V, V keys permuted, no swaps");
+                run<0, 7>("A  + LDS reads, barrier, scalar work");
+                run16<7>("D  + LDS reads, barrier, scalar work");
+            }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0, 0>("A  P.V as 4 x 32x32x16 (the kernel's slot)");
         run16<0>("D  all 16x16x32: 8 K.Q' + 6 P.V, V keys permuted, no swaps");
