@@ -273,6 +273,8 @@ def kernel_records(w, compute):
                     ("pre-packed by the feature store: query pack + flash + merge" if w["store"] == "packed"
                      else "packed per call: pack + flash + merge")}
     roof.update(measured_traffic())
+    if roof.get("clock"):
+        roof["clock"]["frac_at_zero_operand_clock"] = roof["frac"] * roof["clock"]["zero_operands_GHz"] / roof["clock"]["random_operands_GHz"]
     if compute == "f16" and w["store"] == "packed":
         # the same stage with bf16 operands for q.k^T (the arithmetic of earlier rounds' headline, selectable with
         # --compute bf16): the half-precision multipliers cost a few per cent of clock
@@ -570,6 +572,16 @@ def measured_traffic():
             ph = json.load(f)
         out.update(steady_loop_frac=ph.get("steady_loop_frac"), fixed_cost_us=ph.get("fixed_cost_us_per_workgroup"),
                    phases_source="profiles/" + os.path.basename(phases[-1]))
+    # The clock the launch is given: the same cycle count whatever the operands hold, at a clock that follows the
+    # switching in the multipliers (same diagnostic build, operands scaled to zero): `frac` is set by the power
+    # management, not by the schedule.  frac_at_zero_operand_clock scales the live figure by clock alone.
+    clocks = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clock_by_operands.json")))
+    if clocks:
+        with open(clocks[-1]) as f:
+            ck = json.load(f)
+        out["clock"] = {"random_operands_GHz": ck["B1"]["random_operands_GHz"], "zero_operands_GHz": ck["B1"]["zero_operands_GHz"],
+                        "cycles_per_workgroup": ck["B1"]["cycles_per_workgroup"], "peak_assumes_GHz": ck["peak_assumes_GHz"],
+                        "source": "profiles/" + os.path.basename(clocks[-1])}
     return out
 
 
