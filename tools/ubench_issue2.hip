@@ -36,7 +36,7 @@ __device__ __forceinline__ void vop(float& x, float y, float z) {
 
 // MF: 0 none, 1 = 32x32x16 (8 passes), 2 = 16x16x32 (4 passes... per its own shape)
 template <int MF, int K, int OP>
-__global__ void __launch_bounds__(512) bench(float* out, int iters) {
+__global__ void __launch_bounds__(512) bench(float* out, int iters, int rnd) {
     f32x16 acc[4];
     f32x4 acc4[4];
     for (int c = 0; c < 4; ++c) {
@@ -45,6 +45,18 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
     }
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 0.001f); b[i] = (__bf16)(i * 0.01f); }
+    if (rnd) {      // random sign and mantissa, magnitude in [0.5, 2): full switching in the multipliers
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        u4 ua, ub;
+        for (int i = 0; i < 4; ++i) {
+            unsigned h = (threadIdx.x * 2654435761u) ^ ((i + 1) * 40503u + 0x9e3779b9u);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+            ua[i] = (h & 0x80ff80ffu) | 0x3f003f00u;
+            h *= 2654435761u; h ^= h >> 15;
+            ub[i] = (h & 0x80ff80ffu) | 0x3f003f00u;
+        }
+        a = __builtin_bit_cast(bf16x8, ua); b = __builtin_bit_cast(bf16x8, ub);
+    }
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = -0.001f * (threadIdx.x + i);
     float y = 0.5f, z = 0.25f;
@@ -91,15 +103,16 @@ __global__ void __launch_bounds__(512) bench(float* out, int iters) {
 
 static float* g_out;
 static double g_ghz = 2.3;
+static int g_rnd = 0;
 
 template <int MF, int K, int OP>
 double run(int threads) {
     const int grid = 256, iters = 4000;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) bench<MF, K, OP><<<grid, threads>>>(g_out, iters);
+    for (int i = 0; i < 2; ++i) bench<MF, K, OP><<<grid, threads>>>(g_out, iters, g_rnd);
     (void)hipEventRecord(e0);
-    bench<MF, K, OP><<<grid, threads>>>(g_out, iters);
+    bench<MF, K, OP><<<grid, threads>>>(g_out, iters, g_rnd);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -127,7 +140,20 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i) run<1, 0, ADD>(256);
     g_ghz = 32.0 / run<1, 0, ADD>(256);
     printf("clock from MFMA calibration: %.2f GHz\n", g_ghz);
-    if (argc > 1) {   // any argument: only the half-precision exponential survey
+    if (argc > 1 && argv[1][0] == 'p') {   // "peak": back-to-back MFMAs alone, near-constant against random operand bits
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            g_rnd = rnd;
+            for (int threads : {256, 512}) {
+                // 4 SIMDs x 256 CUs; a 32x32x16 MFMA is 32768 flop, a 16x16x32 one 16384; ns per MFMA per SIMD
+                const double n32 = run<1, 0, ADD>(threads), n16 = run<2, 0, ADD>(threads);
+                printf("%s operands, %d wave(s) per SIMD: 32x32x16 %.2f ns per MFMA = %.0f TFLOP/s | 16x16x32 %.2f ns = %.0f TFLOP/s\n",
+                       rnd ? "random" : "near-constant", threads / 256, n32 / (threads / 256), (threads / 256) * 1024 * 32768.0 / n32 / 1e3,
+                       n16 / (threads / 256), (threads / 256) * 1024 * 16384.0 / n16 / 1e3);
+            }
+        }
+        return 0;
+    }
+    if (argc > 1) {   // any other argument: only the half-precision exponential survey
         sweep<0, EXP>("no mfma + exp_f32");
         sweep<0, EXP16>("no mfma + exp_f16");
         sweep<0, EXP16HI>("no mfma + exp_f16 hi");
