@@ -884,9 +884,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
                     ro[NKL + i] = (KU + un * 64) * 16;
                 }
             }
-            for (int it = it0; it < it1; ++it) {
-                const u32x4* L = lds + (it % NB) * SU;
-                const u32x4* Ln = lds + ((it + 1) % NB) * SU;
+            // One stage; `buf` is the ring buffer it lives in (it % NB).
+            auto stage = [&](int it, int buf) {
+                const u32x4* L = lds + buf * SU;
+                const u32x4* Ln = lds + ((buf + 1) % NB) * SU;
                 if (wave_live)
                     static_for<0, U - 1>([&](auto uc) { pipe.template slot<decltype(uc)::value>(L, Ln, lane, qf, O, rs); });
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * NL) : "memory");
@@ -894,7 +895,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
                 // unconditional (no branch in the loop body): past the end the last stage is copied again
                 // into the buffer that has just become free, which nothing reads
                 {
-                    const unsigned bb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((it % NB) * SU) * 16);
+                    const unsigned bb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * SU) * 16);
                     const bool more = it + 1 + NB < slen;
                     const int stepk = more ? KU : 0, stepv = more ? VU : 0;
 #pragma unroll
@@ -904,6 +905,23 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || QT > 2) ? 1 : 2) flash_ke
                     }
                 }
                 if (wave_live) pipe.template slot<U - 1>(L, Ln, lane, qf, O, rs);
+            };
+#ifndef SID_NO_UNROLL2
+            if constexpr (NB == 2) {
+                // two stages per trip: the ring buffer of every fragment read and stage copy is then a constant
+                // (an immediate offset) instead of scalar arithmetic on the stage's parity, which costs issue
+                // slots of the in-order stream in every stage
+                int it = it0;
+                if (it < it1 && (it & 1)) { stage(it, 1); ++it; }
+                for (; it + 1 < it1; it += 2) {
+                    stage(it, 0);
+                    stage(it + 1, 1);
+                }
+                if (it < it1) stage(it, 0);
+            } else
+#endif
+            {
+                for (int it = it0; it < it1; ++it) stage(it, it % NB);
             }
             if (wave_live) { pipe.finish(O); pipe.fold(rs); }
             nissued = max(nissued, min(slen, it1 + NB));
