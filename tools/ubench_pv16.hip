@@ -265,6 +265,8 @@ int main(int argc, char** argv) {
                 run16<0>("D  all 16x16x32: 8 K.Q' + 6 P.V, V keys permuted, no swaps");
                 run<0, 7>("A  + LDS reads, barrier, scalar work");
                 run16<7>("D  + LDS reads, barrier, scalar work");
+                run<1, 7>("B  P.V as 6 x 16x16x32 + 4 swaps, + LDS reads, barrier, scalar work");
+                run<3, 7>("C  P.V rows 0..31 32x32x16, rows 32..47 16x16x32 + 4 swaps, + extras");
             }
         return 0;
     }
