@@ -276,7 +276,7 @@ def kernel_records(w, compute):
     if roof.get("clock"):
         roof["clock"]["frac_at_zero_operand_clock"] = roof["frac"] * roof["clock"]["zero_operands_GHz"] / roof["clock"]["random_operands_GHz"]
     if compute == "f16" and w["store"] == "packed":
-        # the same stage with bf16 operands for q.k^T (the arithmetic of earlier rounds' headline, selectable with
+        # the same stage with bf16 operands for q.k^T (the bf16-throughout arithmetic, selectable with
         # --compute bf16): the half-precision multipliers cost a few per cent of clock
         import torch
         gen = torch.Generator(device=layer["mask"].device); gen.manual_seed(99)
